@@ -1,0 +1,328 @@
+// capi.hip -- the extern "C" launcher ABI of include/hexl_mi355x.h: contexts, keyswitch plans
+// (host precompute + upload), host-pointer staging variants, and the hipEvent timing hook.
+#include <string.h>
+
+#include <algorithm>
+
+#include "hexl_internal.hpp"
+#include "number_theory.hpp"
+
+// ------------------------------------------------------------------------------- context
+int hx_reserve_device(hexl_ctx* ctx, void** p, size_t* cur, size_t need) {
+    if (*cur >= need) return 0;
+    if (*p) { HX_CHECK(hipStreamSynchronize(ctx->stream)); HX_CHECK(hipFree(*p)); *p = nullptr; *cur = 0; }
+    HX_CHECK(hipMalloc(p, need));
+    *cur = need;
+    return 0;
+}
+int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need) {
+    if (*cur >= need) return 0;
+    if (*p) { HX_CHECK(hipStreamSynchronize(ctx->stream)); HX_CHECK(hipHostFree(*p)); *p = nullptr; *cur = 0; }
+    HX_CHECK(hipHostMalloc(p, need, hipHostMallocDefault));
+    *cur = need;
+    return 0;
+}
+
+extern "C" int hexl_ctx_create(int device, hexl_ctx** out) {
+    if (!out) return HEXL_E_BADARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) return HEXL_E_NODEVICE;
+    HX_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HX_CHECK(hipGetDeviceProperties(&prop, device));
+    hexl_ctx* c = new hexl_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    snprintf(c->name, sizeof(c->name), "hexl_mi355x: device %d %s (%s), %d CUs, %.1f GiB", device, prop.name,
+             prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+    HX_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_meta) (void)hipFree(c->d_meta);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int hexl_ctx_set_stream(hexl_ctx* c, void* s) {
+    if (!c) return HEXL_E_BADARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+extern "C" int hexl_ctx_sync(hexl_ctx* c) {
+    if (!c) return HEXL_E_BADARG;
+    HX_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int hexl_ctx_describe(hexl_ctx* c, char* buf, size_t len) {
+    if (!c || !buf || !len) return HEXL_E_BADARG;
+    snprintf(buf, len, "%s", c->name);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- K1..K3
+static bool supported_ntt_n(u64 n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+
+extern "C" int hexl_ntt_fwd(hexl_ctx* c, uint64_t* x, size_t batch, const uint64_t* roots, const uint64_t* precon,
+                            uint64_t q, uint64_t n) {
+    if (!c || !x || !roots || !precon || !q || !supported_ntt_n(n) || batch > 0x7fffffffu) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    return hx_launch_ntt_fwd(c, x, batch, roots, precon, q, n);
+}
+
+extern "C" int hexl_ntt_inv(hexl_ctx* c, uint64_t* x, size_t batch, const uint64_t* ir, const uint64_t* ip, uint64_t q,
+                            uint64_t inv_n, uint64_t inv_n_w, uint64_t n) {
+    if (!c || !x || !ir || !ip || !q || !supported_ntt_n(n) || batch > 0x7fffffffu) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    // floor(y*2^64/q) once on the host; the reference recomputes it per element on the device
+    // (MultiplyUIntModLazy3, device/mod_ops.hpp:135-151)
+    return hx_launch_ntt_inv(c, x, batch, ir, ip, q, inv_n, hx_shoup(inv_n, q), inv_n_w, hx_shoup(inv_n_w, q), n);
+}
+
+extern "C" int hexl_dyadic_multiply(hexl_ctx* c, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t batch,
+                                    uint64_t n, const uint64_t* moduli, uint64_t n_moduli) {
+    if (!c || !out || !a || !b || !moduli) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    return hx_launch_dyadic(c, out, a, b, batch, n, moduli, n_moduli);
+}
+
+// ------------------------------------------------------------------------------- K4 plan
+static u32 ks_loge(u32 logn) { return logn <= 10 ? 4 : 5; }
+static u32 ks_idxB(u32 logn, u32 r, u32 tid) {
+    const u32 loge = ks_loge(logn), P = (logn + loge - 1) / loge, KL = logn - (P - 1) * loge;
+    return ((r >> KL) << (logn - loge + KL)) + (tid << KL) + (r & ((1u << KL) - 1));
+}
+
+extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t K, uint64_t rns, uint64_t kcc,
+                                   const uint64_t* h_moduli, const uint64_t* h_modswitch, const uint64_t* h_twiddles,
+                                   hexl_ks_plan** out) {
+    if (!c || !out || !h_moduli || !h_modswitch) return HEXL_E_BADARG;
+    if (!supported_ntt_n(n) || kcc != 2 || L == 0 || K < 2 || L >= K || K > 16 || rns == 0) return HEXL_E_BADARG;
+    for (u64 i = 0; i < K; ++i)
+        if (h_moduli[i] < (1ULL << 16) || h_moduli[i] >= (1ULL << 60)) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    u32 logn = 0;
+    while ((1ULL << logn) < n) ++logn;
+
+    hexl_ks_plan* p = new hexl_ks_plan();
+    p->ctx = c; p->n = (u32)n; p->logn = logn; p->L = (u32)L; p->K = (u32)K; p->rns = (u32)rns;
+    p->moduli.assign(h_moduli, h_moduli + K);
+
+    const u64 q_sp = h_moduli[K - 1];
+    std::vector<KsModulus> mods(K);
+    std::vector<u64> tables(size_t(K) * 4 * n);
+    std::vector<u64> inv0(n);
+    for (u64 i = 0; i < K; ++i) {
+        const u64 q = h_moduli[i];
+        u64* roots = &tables[(i * 4 + 0) * n];
+        u64* precon = &tables[(i * 4 + 1) * n];
+        u64* iroots = &tables[(i * 4 + 2) * n];
+        u64* iprecon = &tables[(i * 4 + 3) * n];
+        if (h_twiddles) {
+            // caller blocks [inv_roots | precon_inv | roots | precon_roots]; like the reference's
+            // twiddle_generator.hpp:35-79 only blocks 0 and 2 are consumed
+            memcpy(inv0.data(), h_twiddles + i * 4 * n, n * sizeof(u64));
+            memcpy(roots, h_twiddles + (i * 4 + 2) * n, n * sizeof(u64));
+        } else {
+            const u64 w = hxnt::minimal_primitive_root(2 * n, q);      // fpga.cpp:1097-1109
+            hxnt::forward_roots(n, logn, q, w, roots);
+            hxnt::inverse_roots_from0(n, q, roots, inv0.data());
+        }
+        // internal inverse table uses the standalone kernel's indexing (first entry at index 1)
+        iroots[0] = 1;
+        for (u64 r = 1; r < n; ++r) iroots[r] = inv0[r - 1];
+        for (u64 r = 0; r < n; ++r) {
+            precon[r] = hx_shoup(roots[r], q);
+            iprecon[r] = hx_shoup(iroots[r], q);
+        }
+        KsModulus& m = mods[i];
+        m.q = q;
+        m.qbarr = (u64)(((u128)1 << 64) / q);                           // fpga.cpp:1053
+        m.inv_n = hxnt::invmod(n, q);                                   // fpga.cpp:1073
+        m.inv_n_p = hx_shoup(m.inv_n, q);
+        m.inv_n_w = hxnt::mulmod(m.inv_n, iroots[n - 1] % q, q);        // last-stage W folded into the scaling
+        m.inv_n_w_p = hx_shoup(m.inv_n_w, q);
+        u64 msf = h_modswitch[i];                                       // ReduceMod<8>, fpga.cpp:1057-1061
+        if (msf >= 4 * q) msf -= 4 * q;
+        if (msf >= 2 * q) msf -= 2 * q;
+        if (msf >= q) msf -= q;
+        m.msf = msf;
+        m.msf_p = hx_shoup(msf, q);
+        m.half = q_sp >> 1;
+        m.fix = q - (m.half % q);                                       // intt2_redu.hpp:31-32
+        u32 fl = 63;
+        while (!(q >> fl)) --fl;
+        m.len = fl - 1;
+        m.barr_lo = (u64)(((u128)1 << (m.len + 64)) / q);
+    }
+    HX_CHECK(hipMalloc((void**)&p->d_mods, K * sizeof(KsModulus)));
+    HX_CHECK(hipMalloc((void**)&p->d_tables, tables.size() * sizeof(u64)));
+    HX_CHECK(hipMalloc((void**)&p->d_keys, size_t(L) * (L + 1) * 2 * n * sizeof(u64)));
+    HX_CHECK(hipMemcpy(p->d_mods, mods.data(), K * sizeof(KsModulus), hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(u64), hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
+    if (!p) return 0;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->d_mods) (void)hipFree(p->d_mods);
+    if (p->d_tables) (void)hipFree(p->d_tables);
+    if (p->d_keys) (void)hipFree(p->d_keys);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
+    delete p;
+    return 0;
+}
+
+// The reference packs keys into 3x256-bit DDR words (KeySwitch_load_keys, fpga.cpp:1167-1248); the GPU
+// keeps plain 64-bit words but permutes each (d, slot, k) limb into the forward transform's register
+// order so the key multiply-accumulate reads them fully coalesced.
+extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) {
+    if (!p || !h_keys) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(p->ctx->device));
+    const u64 n = p->n, L = p->L, K = p->K;
+    const u32 loge = ks_loge(p->logn), E = 1u << loge, T = (u32)(n >> loge);
+    std::vector<u32> perm(n);
+    for (u32 r = 0; r < E; ++r)
+        for (u32 t = 0; t < T; ++t) perm[r * T + t] = ks_idxB(p->logn, r, t);
+    std::vector<u64> dev(size_t(L) * (L + 1) * 2 * n);
+    for (u64 d = 0; d < L; ++d) {
+        if (!h_keys[d]) return HEXL_E_BADARG;
+        for (u64 slot = 0; slot <= L; ++slot) {
+            const u64 i = slot < L ? slot : K - 1;
+            for (u64 k = 0; k < 2; ++k) {
+                const u64* src = h_keys[d] + (k * K + i) * n;            // fpga.cpp:1186-1190
+                u64* dst = &dev[((d * (L + 1) + slot) * 2 + k) * n];
+                for (u64 j = 0; j < n; ++j) dst[j] = src[perm[j]];
+            }
+        }
+    }
+    HX_CHECK(hipStreamSynchronize(p->ctx->stream));
+    HX_CHECK(hipMemcpy(p->d_keys, dev.data(), dev.size() * sizeof(u64), hipMemcpyHostToDevice));
+    p->have_keys = true;
+    return 0;
+}
+
+extern "C" int hexl_keyswitch(hexl_ks_plan* p, uint64_t* d_result, const uint64_t* d_t_target, size_t batch) {
+    if (!p || !d_result || !d_t_target) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(p->ctx->device));
+    return hx_launch_keyswitch(p, d_result, d_t_target, batch, 7, nullptr);
+}
+
+extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const uint64_t* d_t_target, size_t batch,
+                                   int iters, float* ms_out) {
+    if (!p || !ms_out || iters <= 0) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(p->ctx->device));
+    hipEvent_t ev[4];
+    for (auto& e : ev) HX_CHECK(hipEventCreate(&e));
+    float acc[4] = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        int rc = hx_launch_keyswitch(p, d_result, d_t_target, batch, 7, ev);
+        if (rc) return rc;
+        HX_CHECK(hipEventSynchronize(ev[3]));
+        float t;
+        HX_CHECK(hipEventElapsedTime(&t, ev[0], ev[3])); acc[0] += t;
+        for (int s = 0; s < 3; ++s) { HX_CHECK(hipEventElapsedTime(&t, ev[s], ev[s + 1])); acc[1 + s] += t; }
+    }
+    for (int s = 0; s < 4; ++s) ms_out[s] = acc[s] / iters;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- host-pointer variants
+// The reference stages every batch through device-visible memory (FPGAObject_*::fill_in_data /
+// fill_out_data, host/src/fpga.cpp:329-518); same here with one pinned bounce buffer per context.
+static int stage_reserve(hexl_ctx* c, size_t bytes) {
+    int rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, bytes);
+    if (rc) return rc;
+    return hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, bytes);
+}
+
+extern "C" int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* h_x, size_t batch, const uint64_t* h_roots,
+                                 const uint64_t* h_precon, uint64_t q, uint64_t n) {
+    if (!c || !h_x || !h_roots || !h_precon || !supported_ntt_n(n)) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    const size_t data = batch * n * 8, tab = n * 8;
+    int rc = stage_reserve(c, data + 2 * tab);
+    if (rc) return rc;
+    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
+    memcpy(h, h_roots, tab); memcpy(h + tab, h_precon, tab); memcpy(h + 2 * tab, h_x, data);
+    HX_CHECK(hipMemcpyAsync(d, h, data + 2 * tab, hipMemcpyHostToDevice, c->stream));
+    rc = hexl_ntt_fwd(c, (u64*)(d + 2 * tab), batch, (u64*)d, (u64*)(d + tab), q, n);
+    if (rc) return rc;
+    HX_CHECK(hipMemcpyAsync(h + 2 * tab, d + 2 * tab, data, hipMemcpyDeviceToHost, c->stream));
+    HX_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(h_x, h + 2 * tab, data);
+    return 0;
+}
+
+extern "C" int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* h_x, size_t batch, const uint64_t* h_ir, const uint64_t* h_ip,
+                                 uint64_t q, uint64_t inv_n, uint64_t inv_n_w, uint64_t n) {
+    if (!c || !h_x || !h_ir || !h_ip || !supported_ntt_n(n)) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    const size_t data = batch * n * 8, tab = n * 8;
+    int rc = stage_reserve(c, data + 2 * tab);
+    if (rc) return rc;
+    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
+    memcpy(h, h_ir, tab); memcpy(h + tab, h_ip, tab); memcpy(h + 2 * tab, h_x, data);
+    HX_CHECK(hipMemcpyAsync(d, h, data + 2 * tab, hipMemcpyHostToDevice, c->stream));
+    rc = hexl_ntt_inv(c, (u64*)(d + 2 * tab), batch, (u64*)d, (u64*)(d + tab), q, inv_n, inv_n_w, n);
+    if (rc) return rc;
+    HX_CHECK(hipMemcpyAsync(h + 2 * tab, d + 2 * tab, data, hipMemcpyDeviceToHost, c->stream));
+    HX_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(h_x, h + 2 * tab, data);
+    return 0;
+}
+
+extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* h_out, const uint64_t* h_a, const uint64_t* h_b,
+                                         size_t batch, uint64_t n, const uint64_t* h_moduli, uint64_t n_moduli) {
+    if (!c || !h_out || !h_a || !h_b || !h_moduli) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(c->device));
+    const size_t in = batch * 2 * n_moduli * n * 8, outb = batch * 3 * n_moduli * n * 8, mod = batch * n_moduli * 8;
+    const size_t mod_pad = (mod + 255) & ~size_t(255);
+    int rc = stage_reserve(c, 2 * in + outb + mod_pad);
+    if (rc) return rc;
+    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
+    memcpy(h, h_moduli, mod); memcpy(h + mod_pad, h_a, in); memcpy(h + mod_pad + in, h_b, in);
+    HX_CHECK(hipMemcpyAsync(d, h, mod_pad + 2 * in, hipMemcpyHostToDevice, c->stream));
+    rc = hexl_dyadic_multiply(c, (u64*)(d + mod_pad + 2 * in), (u64*)(d + mod_pad), (u64*)(d + mod_pad + in), batch, n,
+                              (u64*)d, n_moduli);
+    if (rc) return rc;
+    HX_CHECK(hipMemcpyAsync(h + mod_pad + 2 * in, d + mod_pad + 2 * in, outb, hipMemcpyDeviceToHost, c->stream));
+    HX_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(h_out, h + mod_pad + 2 * in, outb);
+    return 0;
+}
+
+extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, const uint64_t* const* h_t_targets,
+                                   size_t batch) {
+    if (!p || !h_results || !h_t_targets) return HEXL_E_BADARG;
+    hexl_ctx* c = p->ctx;
+    HX_CHECK(hipSetDevice(c->device));
+    const size_t tt = size_t(p->L) * p->n * 8, rs = 2 * tt;
+    int rc = stage_reserve(c, batch * (tt + rs));
+    if (rc) return rc;
+    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
+    for (size_t b = 0; b < batch; ++b) {                                 // copyKeySwitchBatch, fpga.cpp:542-555
+        memcpy(h + b * tt, h_t_targets[b], tt);
+        memcpy(h + batch * tt + b * rs, h_results[b], rs);
+    }
+    HX_CHECK(hipMemcpyAsync(d, h, batch * (tt + rs), hipMemcpyHostToDevice, c->stream));
+    rc = hexl_keyswitch(p, (u64*)(d + batch * tt), (u64*)d, batch);
+    if (rc) return rc;
+    HX_CHECK(hipMemcpyAsync(h + batch * tt, d + batch * tt, batch * rs, hipMemcpyDeviceToHost, c->stream));
+    HX_CHECK(hipStreamSynchronize(c->stream));
+    for (size_t b = 0; b < batch; ++b) memcpy(h_results[b], h + batch * tt + b * rs, rs);
+    return 0;
+}

@@ -1,0 +1,78 @@
+// hexl_internal.hpp -- host-side state shared by the launcher translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "../../include/hexl_mi355x.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef unsigned __int128 u128;
+
+#define HX_CHECK(expr)                                                                       \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            fprintf(stderr, "[hexl_mi355x] %s failed: %s (%s:%d)\n", #expr,                  \
+                    hipGetErrorString(_e), __FILE__, __LINE__);                              \
+            return (int)_e;                                                                  \
+        }                                                                                    \
+    } while (0)
+
+struct hexl_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;      // stream launches go to (own or caller's)
+    int num_cu = 0;
+    // grow-only device scratch + pinned staging used by the *_host entry points
+    void* d_stage = nullptr;  size_t d_stage_bytes = 0;
+    void* h_stage = nullptr;  size_t h_stage_bytes = 0;
+    void* d_meta = nullptr;   size_t d_meta_bytes = 0;     // dyadic per-(item,modulus) constants
+    char name[256] = {0};
+};
+
+int hx_reserve_device(hexl_ctx* ctx, void** p, size_t* cur, size_t need);
+int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need);
+
+// per-modulus constants of a keyswitch plan (device copy is an array of K of these)
+struct KsModulus {
+    u64 q;          // modulus
+    u64 qbarr;      // floor(2^64/q)                      (fpga.cpp:1053)
+    u64 inv_n, inv_n_p;       // n^-1 mod q and its Shoup factor (fpga.cpp:1070-1089)
+    u64 inv_n_w, inv_n_w_p;   // n^-1 * W_last and its Shoup factor
+    u64 msf, msf_p;           // modswitch factor reduced mod q (fpga.cpp:1057-1061) + Shoup factor
+    u64 fix;        // q - (floor(q_sp/2) mod q)          (intt2_redu.hpp:31-32)
+    u64 half;       // floor(q_sp/2)                      (intt2_redu.hpp:25)
+    u64 len;        // floor(log2 q) - 1                  (128->64 Barrett, as fpga.cpp:366-373)
+    u64 barr_lo;    // floor(2^(len+64)/q)
+};
+
+struct hexl_ks_plan {
+    hexl_ctx* ctx = nullptr;
+    u32 n = 0, logn = 0, L = 0, K = 0, rns = 0;
+    std::vector<u64> moduli;
+    KsModulus* d_mods = nullptr;      // [K]
+    u64* d_tables = nullptr;          // [K][4][n]: roots, precon, inv_roots(HEXL idx), inv_precon
+    u64* d_keys = nullptr;            // [L][L+1][2][n] in forward-output ("B") order
+    bool have_keys = false;
+    // scratch for `cap` keyswitches in flight: c[cap][L][n], prod[cap][2][L][n], s[cap][2][n]
+    u64* d_scratch = nullptr;
+    size_t cap = 0;
+};
+
+// launcher prototypes implemented per translation unit
+int hx_launch_ntt_fwd(hexl_ctx*, u64* d_x, size_t batch, const u64* roots, const u64* precon, u64 q, u64 n);
+int hx_launch_ntt_inv(hexl_ctx*, u64* d_x, size_t batch, const u64* iroots, const u64* iprecon, u64 q,
+                      u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, u64 n);
+int hx_launch_dyadic(hexl_ctx*, u64* d_out, const u64* d_a, const u64* d_b, size_t batch, u64 n,
+                     const u64* d_moduli, u64 n_moduli);
+int hx_launch_keyswitch(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
+                        hipEvent_t* ev /* optional [4] */);
+// index of coefficient held in register r of thread tid after a forward transform ("B layout")
+u32 hx_idxB(u32 logn, u32 r, u32 tid);
+u32 hx_loge_for(u32 logn);
+
+static inline u64 hx_shoup(u64 y, u64 q) { return (u64)(((u128)(y % q) << 64) / q); }

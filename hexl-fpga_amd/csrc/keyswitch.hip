@@ -1,0 +1,243 @@
+// keyswitch.hip -- K4: the CKKS key-switch pipeline for gfx950 as three fused kernels.
+// Replaces the autorun dataflow of device/keyswitch/ (load.hpp -> intt1 -> intt1_redu -> ntt1 ->
+// dyadmult -> intt2 -> intt2_redu -> ntt2 -> ms -> store.hpp; wiring in
+// autorun_kernel_instances.hpp:43-255) plus the host-side accumulate of fpga.cpp:441-475.
+//
+//   ks_intt    (b, d)          c_d = INTT_{q_d}(t_target[d])                      [SURVEY K4 step 1]
+//   ks_modup   (b, slot)       for d: u = NTT_{q_i}(c_d mod q_i); acc_k += u . key[d][k][i]
+//                              slot < L : prod[k][i] = acc_k                      [steps 2-3]
+//                              slot = L (special prime): s'_k = INTT(acc_k) + floor(q_sp/2)   [step 4]
+//   ks_moddown (b, i, k)       w = NTT_{q_i}((s'_k + fix_i) mod q_i);
+//                              result[k][i] += (prod[k][i] - w) * msf_i  (mod q_i) [steps 5-7]
+//
+// All arithmetic is canonical in the reference (AddUIntMod / SubUIntMod / MultiplyUIntMod), so any
+// exact evaluation matches bit for bit; here the transforms reuse the Harvey lazy butterflies of
+// ntt_core.hpp with a final reduction to [0,q). Intermediates that never leave the GPU (prod, keys)
+// are kept in the forward transform's register order ("B order", [r][tid]) so they are read and
+// written with fully coalesced accesses.
+#include <stdlib.h>
+
+#include "hexl_internal.hpp"
+#include "ntt_core.hpp"
+
+using namespace hx;
+
+// ---- small modular helpers (device/mod_ops.hpp:206-224) -------------------------------------
+__device__ __forceinline__ u64 barrett64(u64 v, u64 q, u64 qbarr) {      // BarrettReduce64 :213-217
+    return csub(v - mulhi(v, qbarr) * q, q);
+}
+__device__ __forceinline__ u64 mulmod128(u64 x, u64 y, u64 q, u32 len, u64 barr_lo) {
+    const u64 lo = x * y, hi = mulhi(x, y);
+    const u64 c1 = (lo >> len) | (hi << (64 - len));                     // q >= 2^16 so len >= 15
+    return csub(lo - mulhi(c1, barr_lo) * q, q);
+}
+
+// Observed dispatch puts block b on XCD b % 8 (MI355X_MICROARCH: workgroup dispatch). Give every XCD a
+// contiguous range of work items so blocks sharing one L2 work on the same RNS slot (same key slabs
+// and twiddle tables). Bijective for any total; affects speed only.
+__device__ __forceinline__ u32 xcd_item(u32 bid, u32 total) {
+    const u32 q = total >> 3, r = total & 7, xcd = bid & 7, j = bid >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+struct KsArgs {
+    const KsModulus* mods;   // [K]
+    const u64* tables;       // [K][4][n]
+    const u64* keys;         // [L][L+1][2][n]  B order
+    u64* c;                  // [chunk][L][n]      natural order
+    u64* prod;               // [chunk][2][L][n]   B order
+    u64* s;                  // [chunk][2][n]      natural order
+    const u64* t_target;     // [chunk][L][n]
+    u64* result;             // [chunk][2][L][n]
+    u32 L, K, nb;            // nb = instances in this chunk
+};
+
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_intt(KsArgs a) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const u32 item = blockIdx.x;                      // item = b*L + d
+    const u32 d = __builtin_amdgcn_readfirstlane(item % a.L);
+    const KsModulus md = a.mods[d];
+    const u64* tb = a.tables + size_t(d) * 4 * G::N;
+    const u64* src = a.t_target + size_t(item) * G::N;
+    u64 v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = src[G::idxB(r, tid)];
+    WgNtt<LOGN, LOGE>::inverse(v, lds, tid, tb + 2 * G::N, tb + 3 * G::N, md.q, md.inv_n, md.inv_n_p, md.inv_n_w,
+                               md.inv_n_w_p);
+    u64* dst = a.c + size_t(item) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = v[r];
+}
+
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_modup(KsArgs a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNtt<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = xcd_item(blockIdx.x, gridDim.x);  // slot-major: item = slot*nb + b
+    // integer division runs on the VALU; pin the (uniform) results back into SGPRs so table bases stay scalar
+    const u32 slot = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - slot * a.nb;
+    const u32 i = slot < L ? slot : a.K - 1;            // special prime = moduli[K-1] (load.hpp:79-84)
+    const KsModulus md = a.mods[i];
+    const u64 q = md.q;
+    const u32 len = u32(md.len);
+    const u64* tb = a.tables + size_t(i) * 4 * G::N;
+
+    u64 acc0[G::E], acc1[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) acc0[r] = acc1[r] = 0;
+
+    for (u32 d = 0; d < L; ++d) {
+        const u64* cd = a.c + (size_t(b) * L + d) * G::N;
+        u64 v[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = barrett64(cd[G::idxA(r, tid)], q, md.qbarr);   // intt1_redu.hpp:36-42
+        const u64* roots = opaque(tb);                  // keep twiddle loads inside the d loop
+        W::forward_lazy(v, lds, tid, roots, roots + G::N, q);
+        W::final_reduce(v, q);
+        const u64* k0 = a.keys + ((size_t(d) * (L + 1) + slot) * 2) * G::N;
+        const u64* k1 = k0 + G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {                 // dyadmult.hpp:128-140
+            const u64 key0 = k0[r * G::T + tid], key1 = k1[r * G::T + tid];
+            acc0[r] = csub(acc0[r] + mulmod128(v[r], key0, q, len, md.barr_lo), q);
+            acc1[r] = csub(acc1[r] + mulmod128(v[r], key1, q, len, md.barr_lo), q);
+        }
+    }
+
+    if (slot < L) {
+        u64* p0 = a.prod + ((size_t(b) * 2 + 0) * L + slot) * G::N;
+        u64* p1 = a.prod + ((size_t(b) * 2 + 1) * L + slot) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { p0[r * G::T + tid] = acc0[r]; p1[r * G::T + tid] = acc1[r]; }
+    } else {
+        // special-prime limb: INTT, then + floor(q_sp/2) mod q_sp (intt2_redu.hpp:25,43)
+        const u64* it = opaque(tb) + 2 * G::N;
+        W::inverse(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        u64* s0 = a.s + (size_t(b) * 2 + 0) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) s0[G::idxA(r, tid)] = csub(acc0[r] + md.half, q);
+        it = opaque(tb) + 2 * G::N;
+        W::inverse(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        u64* s1 = a.s + (size_t(b) * 2 + 1) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) s1[G::idxA(r, tid)] = csub(acc1[r] + md.half, q);
+    }
+}
+
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_moddown(KsArgs a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNtt<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = xcd_item(blockIdx.x, gridDim.x);  // limb-major: item = (i*2 + k)*nb + b
+    const u32 ik = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - ik * a.nb;
+    const u32 i = ik >> 1, k = ik & 1;
+    const KsModulus md = a.mods[i];
+    const u64 q = md.q;
+    const u64* tb = a.tables + size_t(i) * 4 * G::N;
+
+    const u64* sk = a.s + (size_t(b) * 2 + k) * G::N;
+    u64 v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = barrett64(sk[G::idxA(r, tid)] + md.fix, q, md.qbarr);   // intt2_redu.hpp:49-51
+    W::forward_lazy(v, lds, tid, tb, tb + G::N, q);
+    W::final_reduce(v, q);
+
+    const u64* pk = a.prod + ((size_t(b) * 2 + k) * L + i) * G::N;
+    u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const u64 in = csub(pk[r * G::T + tid] + q - v[r], q);                   // ms.hpp:70-78 (canonical)
+        const u64 out = csub(lazy_mul(in, md.msf, md.msf_p, q), q);              // ms.hpp:80-82
+        const int idx = G::idxB(r, tid);
+        const u64 rr = res[idx] + out;                                           // fpga.cpp:453-457
+        res[idx] = rr >= q ? rr - q : rr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int LOGN, int LOGE>
+static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_t* ev) {
+    using G = Geom<LOGN, LOGE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HX_CHECK(hipFuncSetAttribute((const void*)k_ks_intt<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)G::LDS_BYTES));
+        HX_CHECK(hipFuncSetAttribute((const void*)k_ks_modup<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)G::LDS_BYTES));
+        HX_CHECK(hipFuncSetAttribute((const void*)k_ks_moddown<LOGN, LOGE>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipStream_t st = p->ctx->stream;
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1)
+        hipLaunchKernelGGL((k_ks_intt<LOGN, LOGE>), dim3(a.nb * a.L), dim3(G::T), G::LDS_BYTES, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (stage_mask & 2)
+        hipLaunchKernelGGL((k_ks_modup<LOGN, LOGE>), dim3(a.nb * (a.L + 1)), dim3(G::T), G::LDS_BYTES, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
+    if (stage_mask & 4)
+        hipLaunchKernelGGL((k_ks_moddown<LOGN, LOGE>), dim3(a.nb * a.L * 2), dim3(G::T), G::LDS_BYTES, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[3], st));
+    return (int)hipGetLastError();
+}
+
+static size_t ks_chunk_default() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("HEXL_KS_CHUNK");
+        v = e ? atol(e) : 256;
+        if (v < 1) v = 1;
+    }
+    return (size_t)v;
+}
+
+size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
+    const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    return chunk * (size_t(3) * p->L + 2) * p->n * sizeof(u64);
+}
+
+int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
+                        hipEvent_t* ev) {
+    if (!batch) return 0;
+    if (!p->have_keys) return HEXL_E_NOKEYS;
+    const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    if (p->cap < chunk) {
+        if (p->d_scratch) HX_CHECK(hipFree(p->d_scratch));
+        p->d_scratch = nullptr; p->cap = 0;
+        HX_CHECK(hipMalloc((void**)&p->d_scratch, chunk * (size_t(3) * p->L + 2) * p->n * sizeof(u64)));
+        p->cap = chunk;
+    }
+    const size_t n = p->n, L = p->L;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        KsArgs a;
+        a.mods = p->d_mods; a.tables = p->d_tables; a.keys = p->d_keys;
+        a.c = p->d_scratch;
+        a.prod = a.c + p->cap * L * n;
+        a.s = a.prod + p->cap * 2 * L * n;
+        a.t_target = d_t_target + b0 * L * n;
+        a.result = d_result + b0 * 2 * L * n;
+        a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+        int rc;
+        switch (p->logn) {
+            case 10: rc = run_chunk<10, 4>(p, a, stage_mask, ev); break;
+            case 11: rc = run_chunk<11, 5>(p, a, stage_mask, ev); break;
+            case 12: rc = run_chunk<12, 5>(p, a, stage_mask, ev); break;
+            case 13: rc = run_chunk<13, 5>(p, a, stage_mask, ev); break;
+            case 14: rc = run_chunk<14, 5>(p, a, stage_mask, ev); break;
+            default: rc = HEXL_E_BADARG;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,260 @@
+// ntt_core.hpp -- workgroup-level negacyclic NTT / INTT for gfx950 (CDNA4), 64-bit Harvey/Shoup
+// lazy butterflies, op-for-op identical to the reference FPGA kernels:
+//   forward : device/fwd_ntt.cpp:289-385   (== tests/test_utils/ntt.cpp:474-548)
+//   inverse : device/inv_ntt.cpp:286-437   (== tests/test_utils/ntt.cpp:580-659)
+//
+// MI355X mapping (one workgroup == one polynomial):
+//   * N = 2^LOGN coefficients live in registers, E = 2^LOGE per thread, T = N/E threads.
+//   * A transform is P = ceil(LOGN/LOGE) register passes of up to LOGE radix-2 stages each
+//     (a radix-E butterfly network with static register indices); between passes the
+//     polynomial is re-dealt to the threads through LDS (N*8 B + padding <= 160 KiB/CU).
+//   * "A layout"  idx = r*T + tid          : wave reads/writes 512-B contiguous runs of HBM
+//     "B layout"  idx = hi(r)*.. + tid*2^KL + lo(r): each lane owns 2^KL contiguous words.
+//     forward goes A -> B, inverse goes B -> A, so INTT(NTT(x)) needs no data movement and
+//     every intermediate a caller never sees can stay in "B order" ([r][tid], coalesced).
+//   * twiddles come from the caller's tables (bit-reversed order) through L2; the first
+//     pass's indices are uniform so the compiler emits scalar loads for them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Optional scheduling fences inside the unrolled butterfly networks (every HX_FENCE_EVERY twiddles).
+#ifndef HX_FENCE_EVERY
+#define HX_FENCE_EVERY 0   /* 0 = no fences (measured: not needed once LICM is blocked, see opaque()) */
+#endif
+#if HX_FENCE_EVERY > 0
+#define HX_SCHED_FENCE(j) do { if ((((j) + 1) % HX_FENCE_EVERY) == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HX_SCHED_FENCE(j) do { } while (0)
+#endif
+
+namespace hx {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+__device__ __forceinline__ u64 mulhi(u64 a, u64 b) { return __umul64hi(a, b); }
+
+// Harvey lazy product  W*x - hi64(W'*x)*q   (mod 2^64)   -- fwd_ntt.cpp:336-354, mod_ops.hpp:153-162
+__device__ __forceinline__ u64 lazy_mul(u64 x, u64 w, u64 wp, u64 q) { return w * x - mulhi(x, wp) * q; }
+
+__device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
+
+// Twiddle loads do not depend on the loop a transform sits in (polynomial / decomposition index), so
+// LICM hoists ALL of them out of that loop and the register allocator spills hundreds of VGPRs
+// (measured: 0 -> 250 spills). Laundering the table pointer inside the loop body pins the loads.
+template <class T>
+__device__ __forceinline__ const T* opaque(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <int LOGN, int LOGE>
+struct Geom {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int E = 1 << LOGE;
+    static constexpr int T = N / E;                        // threads per workgroup
+    static constexpr int P = (LOGN + LOGE - 1) / LOGE;     // register passes
+    static constexpr int KL = LOGN - (P - 1) * LOGE;       // stages in the partial pass
+    static constexpr int NG = 1 << (LOGE - KL);            // independent groups in that pass
+    // LDS padding: +1 word per 16 keeps 17-word lane strides conflict-free for ds_*_b64,
+    // +16 words per 512 puts consecutive 512-word runs on opposite bank halves.
+    static constexpr int LDS_WORDS = N + (N >> 4) + ((N >> 9) << 4);
+    static constexpr size_t LDS_BYTES = size_t(LDS_WORDS) * 8;
+
+    __device__ static __forceinline__ int pad(int idx) { return idx + (idx >> 4) + ((idx >> 9) << 4); }
+    __device__ static __forceinline__ int idxA(int r, int tid) { return r * T + tid; }
+    __device__ static __forceinline__ int idxB(int r, int tid) {
+        return ((r >> KL) << (LOGN - LOGE + KL)) + (tid << KL) + (r & ((1 << KL) - 1));
+    }
+    // full pass whose LOGE active index bits start at bit LO
+    template <int LO>
+    __device__ static __forceinline__ int idxF(int r, int tid) {
+        return ((tid >> LO) << (LO + LOGE)) + (r << LO) + (tid & ((1 << LO) - 1));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// register butterfly networks. `v` is the thread's E words, OFF the first register of the group.
+// ---------------------------------------------------------------------------------------------
+
+// forward: K stages, first one is global stage S0 (1-based, m = 2^(S0-1)); G = index bits above
+// the active field. Twiddle of stage u, sub-block j:  roots[2^(S0-1+u) + (G<<u) + j].
+template <int E, int OFF, int K, int S0>
+__device__ __forceinline__ void fwd_stages(u64 (&v)[E], u32 G, const u64* __restrict__ roots,
+                                           const u64* __restrict__ precon, u64 q, u64 twoq) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const u32 base = (1u << (S0 - 1 + u)) + (G << u);
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const u64 W = roots[base + j];
+            const u64 Wp = precon[base + j];
+#pragma unroll
+            for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
+                const int a0 = OFF + (j << (K - u)) + c;
+                const int a1 = a0 + (1 << (K - 1 - u));
+                const u64 X = v[a0], Y = v[a1];
+                const u64 tx = csub(X, twoq);              // fwd_ntt.cpp:322-323
+                const u64 Q = lazy_mul(Y, W, Wp, q);       // :336-354
+                v[a0] = tx + Q;                            // :359
+                v[a1] = tx + twoq - Q;                     // :360
+            }
+            HX_SCHED_FENCE(j);
+        }
+    }
+}
+
+// inverse: K stages on index bits [LO, LO+K); stage u has t = 2^(LO+u);
+// twiddle index  N - N/2^(LO+u) + 1 + (G << (K-1-u)) + j   (root_index walk of inv_ntt.cpp:141-306).
+// If LAST, the final stage (t = N/2) is the fused n^-1 scaling of inv_ntt.cpp:400-437.
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST>
+__device__ __forceinline__ void inv_stages(u64 (&v)[E], u32 G, const u64* __restrict__ iroots,
+                                           const u64* __restrict__ iprecon, u64 q, u64 twoq,
+                                           u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p) {
+    constexpr u32 N = 1u << LOGN;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool fused = LAST && (u == K - 1);
+        const u32 base = N - (N >> (LO + u)) + 1 + (G << (K - 1 - u));
+#pragma unroll
+        for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
+            u64 W = 0, Wp = 0;
+            if (!fused) { W = iroots[base + j]; Wp = iprecon[base + j]; }
+#pragma unroll
+            for (int c = 0; c < (1 << u); ++c) {
+                const int a0 = OFF + (j << (u + 1)) + c;
+                const int a1 = a0 + (1 << u);
+                const u64 X = v[a0], Y = v[a1];
+                const u64 tx = csub(X + Y, twoq);          // inv_ntt.cpp:300-304
+                const u64 ty = X + twoq - Y;
+                if (!fused) {
+                    v[a0] = tx;
+                    v[a1] = lazy_mul(ty, W, Wp, q);        // :305-306
+                } else {
+                    v[a0] = csub(lazy_mul(tx, inv_n, inv_n_p, q), q);      // :413-432
+                    v[a1] = csub(lazy_mul(ty, inv_n_w, inv_n_w_p, q), q);
+                }
+            }
+            HX_SCHED_FENCE(j);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS re-deal: write registers under the current ownership map, read under the next one.
+// ---------------------------------------------------------------------------------------------
+template <class G, class FromIdx, class ToIdx>
+__device__ __forceinline__ void redeal(u64 (&v)[G::E], u64* lds, int tid, FromIdx from, ToIdx to) {
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) lds[G::pad(from(r, tid))] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = lds[G::pad(to(r, tid))];
+    __syncthreads();
+}
+
+template <int LOGN, int LOGE>
+struct WgNtt {
+    using G = Geom<LOGN, LOGE>;
+    static constexpr int E = G::E;
+
+    // ---- forward: v in A layout on entry, B layout on exit; values in [0,4q) (lazy) ---------
+    template <int PASS>
+    __device__ static __forceinline__ void fwd_pass(u64 (&v)[E], u64* lds, int tid,
+                                                    const u64* roots, const u64* precon, u64 q, u64 twoq) {
+        if constexpr (PASS < G::P - 1) {
+            constexpr int LO = LOGN - (PASS + 1) * LOGE;
+            // pass 0 has no index bits above its field: constant twiddle addresses -> scalar loads
+            const u32 Gp = (PASS == 0) ? 0u : (u32(tid) >> LO);
+            fwd_stages<E, 0, LOGE, PASS * LOGE + 1>(v, Gp, roots, precon, q, twoq);
+            // hand over to the next pass's ownership
+            if constexpr (PASS + 1 < G::P - 1) {
+                constexpr int LO2 = LO - LOGE;
+                redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                          [](int r, int t) { return G::template idxF<LO2>(r, t); });
+            } else {
+                redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                          [](int r, int t) { return G::idxB(r, t); });
+            }
+            fwd_pass<PASS + 1>(v, lds, tid, roots, precon, q, twoq);
+        } else {
+            // partial pass: NG groups of 2^KL contiguous words
+            fwd_last<0>(v, tid, roots, precon, q, twoq);
+        }
+    }
+    template <int GRP>
+    __device__ static __forceinline__ void fwd_last(u64 (&v)[E], int tid, const u64* roots,
+                                                    const u64* precon, u64 q, u64 twoq) {
+        if constexpr (GRP < G::NG) {
+            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            fwd_stages<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1>(v, Gbits, roots, precon, q, twoq);
+            fwd_last<GRP + 1>(v, tid, roots, precon, q, twoq);
+        }
+    }
+    __device__ static __forceinline__ void forward_lazy(u64 (&v)[E], u64* lds, int tid, const u64* roots,
+                                                        const u64* precon, u64 q) {
+        fwd_pass<0>(v, lds, tid, roots, precon, q, q << 1);
+    }
+    // fwd_ntt.cpp:369-384
+    __device__ static __forceinline__ void final_reduce(u64 (&v)[E], u64 q) {
+        const u64 twoq = q << 1;
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = csub(csub(v[r], twoq), q);
+    }
+
+    // ---- inverse: v in B layout on entry, A layout on exit; values in [0,q) -----------------
+    template <int GRP>
+    __device__ static __forceinline__ void inv_first(u64 (&v)[E], int tid, const u64* iroots,
+                                                     const u64* iprecon, u64 q, u64 twoq, u64 a, u64 ap,
+                                                     u64 b, u64 bp) {
+        if constexpr (GRP < G::NG) {
+            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            inv_stages<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1)>(v, Gbits, iroots, iprecon, q,
+                                                                          twoq, a, ap, b, bp);
+            inv_first<GRP + 1>(v, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
+        }
+    }
+    // PASS counts the full passes after the partial one: active bits [KL + PASS*LOGE, +LOGE)
+    template <int PASS>
+    __device__ static __forceinline__ void inv_pass(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
+                                                    const u64* iprecon, u64 q, u64 twoq, u64 a, u64 ap,
+                                                    u64 b, u64 bp) {
+        if constexpr (PASS < G::P - 1) {
+            constexpr int LO = G::KL + PASS * LOGE;
+            if constexpr (PASS == 0) {
+                redeal<G>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
+                          [](int r, int t) { return G::template idxF<LO>(r, t); });
+            } else {
+                constexpr int LOP = LO - LOGE;
+                redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
+                          [](int r, int t) { return G::template idxF<LO>(r, t); });
+            }
+            const u32 Gp = (PASS == G::P - 2) ? 0u : (u32(tid) >> LO);
+            inv_stages<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iroots, iprecon, q, twoq, a, ap, b, bp);
+            inv_pass<PASS + 1>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
+        }
+    }
+    __device__ static __forceinline__ void inverse(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
+                                                   const u64* iprecon, u64 q, u64 inv_n, u64 inv_n_p,
+                                                   u64 inv_n_w, u64 inv_n_w_p) {
+        const u64 twoq = q << 1;
+        inv_first<0>(v, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        inv_pass<0>(v, lds, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+    }
+};
+
+// floor(y * 2^64 / q) computed on the device once per launch (the reference's
+// MultiplyUIntModLazy3 divides per element, mod_ops.hpp:143-145): binary long division, y < q.
+__device__ __forceinline__ u64 shoup_factor(u64 y, u64 q) {
+    u64 rem = y, quo = 0;
+    for (int i = 0; i < 64; ++i) {
+        const bool carry = rem >> 63;
+        rem <<= 1;
+        quo <<= 1;
+        if (carry || rem >= q) { rem -= q; quo |= 1; }
+    }
+    return quo;
+}
+
+}  // namespace hx

@@ -1,0 +1,61 @@
+"""GPU parity: hexl_dyadic_multiply vs the oracle and vs the reference test's inline model
+(tests/test_dyadic_multiply.cpp:32-85: toy non-prime moduli (b+m+1)*10, operands >> 4q)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_style_io(num, nm, n):
+    mod, a, b = [], [], []
+    for bb in range(num):
+        mod += [(bb + m + 1) * 10 for m in range(nm)]
+        i = np.arange(n, dtype=np.uint64)
+        a += [bb + i + 1 + m * n for m in range(nm)] + [bb + i + 11 + m * n for m in range(nm)]
+        b += [bb + i + 2 + m * n for m in range(nm)] + [bb + i + 22 + m * n for m in range(nm)]
+    return (np.array(mod, dtype=np.uint64), np.concatenate(a).astype(np.uint64), np.concatenate(b).astype(np.uint64))
+
+
+def gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm):
+    batch = len(a) // (2 * nm * n)
+    import torch
+    out = torch.empty(batch * 3 * nm * n, dtype=torch.int64, device=dev)
+    ctx.dyadic_multiply(out, hx.as_i64(a).to(dev), hx.as_i64(b).to(dev), hx.as_i64(mod).to(dev), n, nm)
+    ctx.sync()
+    return hx.to_u64(out)
+
+
+@pytest.mark.parametrize("n,nm,num", [(512, 1, 2), (1024, 2, 16), (4096, 7, 3), (16384, 14, 2), (32768, 4, 2)])
+def test_reference_toy_moduli(hx, ctx, dev, orc, n, nm, num):
+    mod, a, b = ref_style_io(num, nm, n)
+    got = gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm).reshape(num, 3, nm, n)
+    A, B = a.reshape(num, 2, nm, n).astype(object), b.reshape(num, 2, nm, n).astype(object)
+    M = mod.reshape(num, nm).astype(object)[:, :, None]
+    assert np.array_equal(got[:, 0].astype(object), (A[:, 0] * B[:, 0]) % M)
+    assert np.array_equal(got[:, 1].astype(object), (A[:, 0] * B[:, 1] + A[:, 1] * B[:, 0]) % M)
+    assert np.array_equal(got[:, 2].astype(object), (A[:, 1] * B[:, 1]) % M)
+
+
+@pytest.mark.parametrize("bits", [30, 52, 61])
+def test_prime_moduli_vs_oracle(hx, ctx, dev, orc, bits):
+    n, nm, batch = 8192, 4, 3
+    mod1 = np.array(orc.primes(nm, bits, n), dtype=np.uint64)
+    rng = np.random.default_rng(bits)
+    a = np.concatenate([rng.integers(0, int(m), size=n, dtype=np.uint64) for _ in range(batch) for _p in range(2) for m in mod1])
+    b = np.concatenate([rng.integers(0, int(m), size=n, dtype=np.uint64) for _ in range(batch) for _p in range(2) for m in mod1])
+    mod = np.tile(mod1, batch)
+    got = gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm).reshape(batch, -1)
+    for k in range(batch):
+        sl = slice(k * 2 * nm * n, (k + 1) * 2 * nm * n)
+        exact = orc.dyadic(a[sl], b[sl], n, mod1, exact=True)
+        assert np.array_equal(got[k], exact)
+        assert np.array_equal(exact, orc.dyadic(a[sl], b[sl], n, mod1, exact=False))   # reference MultMod, in domain
+
+
+def test_arbitrary_64bit_operands(hx, ctx, dev, orc):
+    n, nm = 2048, 3
+    mod = np.array([3, 2**61 - 1, 1000003], dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 2**64 - 1, size=2 * nm * n, dtype=np.uint64)
+    b = rng.integers(0, 2**64 - 1, size=2 * nm * n, dtype=np.uint64)
+    assert np.array_equal(gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm), orc.dyadic(a, b, n, mod, exact=True))

@@ -1,0 +1,74 @@
+"""GPU parity: hexl_keyswitch (3 fused HIP kernels) vs the CPU oracle, bit-exact, for every n the API
+accepts and several (L, K); plus properties at the BASELINE batch size. Mirrors the shape of
+tests/test_keyswitch.cpp:148-191 (vectors 16384_6_7_7_2 / 8192_.., one worksize batch)."""
+import numpy as np
+import pytest
+
+from ks_util import KsCase
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(hx, ctx, dev, case, ts, rs):
+    plan = hx.KeySwitchPlan(ctx, case.n, case.L, case.K, case.rns, 2, case.moduli, case.modswitch, case.twiddles)
+    plan.set_keys(case.keys)
+    t = hx.as_i64(np.concatenate(ts)).to(dev)
+    r = hx.as_i64(np.concatenate(rs)).to(dev)
+    plan.keyswitch(r, t, len(ts))
+    ctx.sync()
+    out = hx.to_u64(r).reshape(len(ts), -1)
+    plan.close()
+    return out
+
+
+@pytest.mark.parametrize("n,L,K", [(1024, 1, 2), (1024, 3, 4), (2048, 2, 3), (4096, 5, 7), (8192, 6, 7),
+                                   (16384, 6, 7), (16384, 7, 8), (16384, 2, 7)])
+def test_vs_oracle(hx, ctx, dev, orc, n, L, K):
+    case = KsCase(orc, n, L, K, seed=n + L)
+    nb = 3 if n >= 8192 else 5
+    ts, rs = zip(*[case.inputs(orc, b) for b in range(nb)])
+    got = run_gpu(hx, ctx, dev, case, ts, rs)
+    for b in range(nb):
+        assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"instance {b}"
+
+
+def test_caller_twiddles_honoured(hx, ctx, dev, orc):
+    """twiddle_factors != nullptr path (tests/test_keyswitch.cpp:73-90 passes the 4-block table)"""
+    case = KsCase(orc, 4096, 3, 4, seed=11, with_twiddles=True)
+    t, r = case.inputs(orc, 0)
+    got = run_gpu(hx, ctx, dev, case, [t], [r])
+    assert np.array_equal(got[0], case.expected(orc, t, r))
+
+
+def test_batch_chunks_and_linearity(hx, ctx, dev, orc, monkeypatch):
+    """batch larger than one scratch chunk; keyswitch is linear in t_target and additive in result"""
+    n, L, K = 16384, 6, 7
+    case = KsCase(orc, n, L, K, seed=5)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, L + 1, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    nb = 300                                    # > default chunk of 256
+    t0, r0 = case.inputs(orc, 0)
+    t1, _ = case.inputs(orc, 1)
+    ts = np.concatenate([t0 if b % 2 == 0 else t1 for b in range(nb)])
+    rs = np.zeros(nb * 2 * L * n, dtype=np.uint64)
+    d_t, d_r = hx.as_i64(ts).to(dev), hx.as_i64(rs).to(dev)
+    plan.keyswitch(d_r, d_t, nb)
+    ctx.sync()
+    out = hx.to_u64(d_r).reshape(nb, -1)
+    e0 = case.expected(orc, t0, np.zeros_like(r0))
+    e1 = case.expected(orc, t1, np.zeros_like(r0))
+    assert np.array_equal(out[0], e0) and np.array_equal(out[1], e1)
+    assert np.array_equal(out[298], e0) and np.array_equal(out[299], e1)
+    assert (out[0::2] == e0).all() and (out[1::2] == e1).all()
+    # linearity: KS(t0 + t1) == KS(t0) + KS(t1) (mod q_i per limb), accumulate: second call adds again
+    qs = np.repeat(case.moduli[:L].astype(object), n)
+    tsum = ((t0.astype(object) + t1.astype(object)) % qs).astype(np.uint64)
+    d_t2, d_r2 = hx.as_i64(tsum).to(dev), hx.as_i64(np.zeros_like(r0)).to(dev)
+    plan.keyswitch(d_r2, d_t2, 1)
+    ctx.sync()
+    q2 = np.tile(qs, 2)
+    assert np.array_equal(hx.to_u64(d_r2).astype(object), (e0.astype(object) + e1.astype(object)) % q2)
+    plan.keyswitch(d_r2, d_t2, 1)
+    ctx.sync()
+    assert np.array_equal(hx.to_u64(d_r2).astype(object), (2 * (e0.astype(object) + e1.astype(object))) % q2)
+    plan.close()

@@ -1,0 +1,112 @@
+"""GPU parity: hexl_ntt_fwd / hexl_ntt_inv (HIP, through the C-ABI) vs the CPU oracle.
+Mirrors tests/test_fwd_ntt.cpp:119-170 and tests/test_inv_ntt.cpp:127-178 of the reference:
+N=16384, primes of 20/32/55/62 "bits", stimuli RANDOM/RAMP/ZEROS/ONES/IMPULSE/ALL_MAX, exact
+equality (bit-exact, including uint64 wrap-around for out-of-range inputs and 4q >= 2^64)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import stimulus
+
+pytestmark = pytest.mark.gpu
+GOLD = json.loads((Path(__file__).parent / "golden" / "ntt_golden.json").read_text())["records"]
+STIMS = ["RANDOM", "RAMP", "ALL_ZEROS", "ALL_ONES", "IMPULSE", "ALL_MAX_VALUES"]
+
+
+def _dev(hx, a, dev):
+    return hx.as_i64(a).to(dev)
+
+
+def run_fwd(hx, ctx, dev, x, t):
+    d = _dev(hx, x, dev)
+    ctx.ntt_fwd(d, _dev(hx, t.roots, dev), _dev(hx, t.precon, dev), t.q, t.n)
+    ctx.sync()
+    return hx.to_u64(d)
+
+
+def run_inv(hx, ctx, dev, x, t):
+    d = _dev(hx, x, dev)
+    ctx.ntt_inv(d, _dev(hx, t.inv_roots, dev), _dev(hx, t.inv_precon, dev), t.q, t.inv_n, t.inv_n_w, t.n)
+    ctx.sync()
+    return hx.to_u64(d)
+
+
+@pytest.mark.parametrize("bits", [20, 32, 55, 62])
+def test_fwd_inv_reference_matrix(hx, ctx, dev, orc, bits):
+    n = 16384
+    q = orc.primes(1, bits, n)[0]
+    t = orc.HexlTables(n, q)
+    x = np.stack([stimulus(k, n, q) for k in STIMS])
+    got = run_fwd(hx, ctx, dev, x, t).reshape(len(STIMS), n)
+    exp = orc.ntt_fwd(x, t)
+    for k, name in enumerate(STIMS):
+        assert np.array_equal(got[k], exp[k]), f"fwd {bits}-bit {name}"
+    got = run_inv(hx, ctx, dev, x, t).reshape(len(STIMS), n)
+    exp = orc.ntt_inv(x, t)
+    for k, name in enumerate(STIMS):
+        assert np.array_equal(got[k], exp[k]), f"inv {bits}-bit {name}"
+
+
+@pytest.mark.parametrize("rec", [r for r in GOLD], ids=lambda r: f"n{r['n']}_b{r['bits']}")
+def test_golden_digests(hx, ctx, dev, orc, rec):
+    """committed fixtures captured from the reference's own CPU oracle"""
+    n, q = rec["n"], rec["q"]
+    t = orc.HexlTables(n, q)
+    assert t.w == rec["w"] and t.inv_n == rec["inv_n"] and t.inv_n_w == rec["inv_n_w"]
+    for name, s in rec["stimuli"].items():
+        x = {"RAMP": np.arange(n, dtype=np.uint64), "ALLMAX": np.full(n, 2**64 - 1, dtype=np.uint64),
+             "SPLITMIX42": orc.splitmix(n, 42, q)}[name]
+        f = run_fwd(hx, ctx, dev, x, t)
+        assert "%016x" % orc.fnv(f) == s["fwd_fnv"], f"fwd {name}"
+        assert [int(v) for v in f[:4]] == s["fwd_head"] and [int(v) for v in f[-4:]] == s["fwd_tail"]
+        i = run_inv(hx, ctx, dev, x, t)
+        assert "%016x" % orc.fnv(i) == s["inv_fnv"], f"inv {name}"
+        assert [int(v) for v in i[:4]] == s["inv_head"] and [int(v) for v in i[-4:]] == s["inv_tail"]
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+def test_all_sizes_random(hx, ctx, dev, orc, n):
+    q = orc.primes(2, 51, n)[1]
+    t = orc.HexlTables(n, q)
+    x = np.stack([orc.splitmix(n, 100 + b, q) for b in range(5)])
+    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t).ravel())
+    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t).ravel())
+
+
+def test_random_tables_like_benchmark(hx, ctx, dev, orc):
+    """benchmark/bench_fwd_ntt.cpp:38-42 feeds RANDOM tables: the kernel must replay the butterflies
+    op for op, not rely on the tables being roots of unity"""
+    n, q = 16384, orc.primes(1, 52, 16384)[0]
+    t = orc.HexlTables(n, q)
+    rng = np.random.default_rng(3)
+    for arr in (t.roots, t.precon, t.inv_roots, t.inv_precon):
+        arr[:] = rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)
+    x = rng.integers(0, 2**64 - 1, size=(3, n), dtype=np.uint64)
+    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t).ravel())
+    t.inv_n, t.inv_n_w = int(rng.integers(0, q)), int(rng.integers(0, q))
+    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t).ravel())
+
+
+def test_full_batch_roundtrip_and_linearity(hx, ctx, dev, orc):
+    """BASELINE config 2: fwd+inv NTT, N=16384, batch=1024 -- size-independent properties"""
+    import torch
+    n, batch = 16384, 1024
+    q = orc.primes(1, 52, n)[0]
+    t = orc.HexlTables(n, q)
+    x = np.stack([orc.splitmix(n, 1000 + b, q) for b in range(batch)])
+    d = _dev(hx, x, dev)
+    tabs = [_dev(hx, a, dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
+    ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)
+    ctx.sync()
+    f = hx.to_u64(d).reshape(batch, n)
+    assert np.array_equal(f[0], orc.ntt_fwd(x[0], t)[0]) and np.array_equal(f[-1], orc.ntt_fwd(x[-1], t)[0])
+    assert int(f.max()) < q
+    # linearity: NTT(a) + NTT(b) == NTT(a + b) mod q
+    s = (x[0].astype(object) + x[1].astype(object)) % q
+    fs = run_fwd(hx, ctx, dev, np.array(s, dtype=np.uint64), t)
+    assert np.array_equal((f[0].astype(object) + f[1].astype(object)) % q, fs.astype(object))
+    ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
+    ctx.sync()
+    assert torch.equal(d.cpu(), hx.as_i64(x).reshape(-1))
