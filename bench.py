@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hexl-fpga hot path on MI355X.
+
+Metric (BASELINE.json): keyswitches/sec at N=16384, decomp_modulus_size=7 (key_modulus_size=8,
+52-bit primes), data resident in HBM; one "step" = one hexl_keyswitch() pass over the rank's batch of
+synthetic ciphertexts. Ranks (one per GPU) each own an independent shard of the batch -- no collective on
+the data path -- so `scaling` is weak and `value` = all ranks' keyswitches / max-over-ranks time.
+
+    python bench.py [--gpus N --steps K --warmup W --batch B]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline`, `cpu_baseline` and `extra`
+(fwd/inv NTT rates, per-stage kernel times, the reference-representable L=6/K=7 shape).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "oracle"))   # checker + cpu_baseline leg only
+
+N = 16384
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
+
+
+def ks_alg_bytes(n, L):
+    """compulsory HBM bytes per keyswitch: read t_target[L][n], read+write result[2][L][n]"""
+    return (L + 2 * 2 * L) * n * 8
+
+
+def device_inputs(hx, orc_mod, case, batch, dev, distinct=8):
+    """batch instances built from `distinct` independent splitmix instances (keeps host prep cheap; every
+    instance is still full-entropy data mod its limb)"""
+    import torch
+    ts, rs = zip(*[case.inputs(orc_mod, b) for b in range(min(distinct, batch))])
+    t = hx.as_i64(np.stack(ts)).to(dev)
+    r = hx.as_i64(np.stack(rs)).to(dev)
+    reps = (batch + t.shape[0] - 1) // t.shape[0]
+    return t.repeat(reps, 1)[:batch].contiguous(), r.repeat(reps, 1)[:batch].contiguous()
+
+
+def time_ntt(hx, ctx, orc_mod, dev, batch, iters):
+    import torch
+    q = orc_mod.primes(1, 51, N)[0]
+    tb = orc_mod.HexlTables(N, q)
+    x = hx.as_i64(np.stack([orc_mod.splitmix(N, 1000 + b, q) for b in range(8)])).to(dev)
+    x = x.repeat((batch + 7) // 8, 1)[:batch].contiguous()
+    tabs = [hx.as_i64(a).to(dev) for a in (tb.roots, tb.precon, tb.inv_roots, tb.inv_precon)]
+    out = {}
+    for name in ("fwd", "inv"):
+        def run():
+            if name == "fwd":
+                ctx.ntt_fwd(x, tabs[0], tabs[1], q, N)
+            else:
+                ctx.ntt_inv(x, tabs[2], tabs[3], q, tb.inv_n, tb.inv_n_w, N)
+        run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        out[name] = {"ms_per_launch": ms, "ntt_per_s": batch / (ms * 1e-3),
+                     "alg_GBps": batch * 2 * N * 8 / (ms * 1e-3) / 1e9}
+    return out
+
+
+def cpu_baseline(orc_mod, case, budget_s=12.0):
+    """the oracle (C restatement of the reference algorithm, single thread) timed on this host"""
+    t, r = case.inputs(orc_mod, 0)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        case.expected(orc_mod, t, r)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 64:
+            break
+    return {"value": done / el, "unit": "keyswitches/s", "cores": 1, "kind": "port",
+            "sample": f"{done} keyswitch(es) N={case.n} L={case.L} K={case.K}, oracle/hexl_oracle.c -O3, 1 thread of "
+                      f"{os.cpu_count()} host cores, {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="keyswitches per GPU per step")
+    ap.add_argument("--decomp", type=int, default=7, help="decomp_modulus_size L (key_modulus_size = L+1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hexl_fpga_amd as hx
+    import orc as orc_mod
+    from ks_util import KsCase
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx = hx.Context(local)
+    L, K = a.decomp, a.decomp + 1
+    case = KsCase(orc_mod, N, L, K, seed=1 + rank)          # every rank: its own shard of ciphertexts
+    plan = hx.KeySwitchPlan(ctx, N, L, K, L + 1, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    d_t, d_r = device_inputs(hx, orc_mod, case, a.batch, dev)
+
+    for _ in range(a.warmup):
+        plan.keyswitch(d_r, d_t, a.batch)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        plan.keyswitch(d_r, d_t, a.batch)
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)                              # HIP events on the launch stream
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    total_ks = a.batch * a.steps * world
+    value = total_ks / elapsed
+    out = {
+        "metric": "keyswitches/sec at N=16384, decomp=7", "value": value, "unit": "keyswitches/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"keyswitch N={N} decomp_modulus_size={L} key_modulus_size={K} 52-bit primes "
+                               f"(GeneratePrimes(K,51,N)), kcc=2, batch {a.batch}/GPU resident in HBM",
+                   "parallelism": f"{world} independent shard(s), no collective"},
+    }
+    if rank == 0:
+        alg = ks_alg_bytes(N, L)
+        ach = alg * a.batch * a.steps / (dev_ms * 1e-3) / 1e9          # this rank, device-timed
+        stage = plan.time_stages(d_r, d_t, min(a.batch, 256), 3)
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "keyswitch pipeline (ks_intt + ks_modup + ks_moddown)",
+                           "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps}
+        extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "ks_intt": stage[1],
+                                                             "ks_modup": stage[2], "ks_moddown": stage[3]},
+                 "device": ctx.describe()}
+        if not a.no_extra:
+            extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)
+            # the reference-representable shape 16384_6_7_7_2 (decomp 6, 7 key moduli)
+            case6 = KsCase(orc_mod, N, 6, 7, seed=99)
+            plan6 = hx.KeySwitchPlan(ctx, N, 6, 7, 7, 2, case6.moduli, case6.modswitch)
+            plan6.set_keys(case6.keys)
+            t6, r6 = device_inputs(hx, orc_mod, case6, a.batch, dev)
+            plan6.keyswitch(r6, t6, a.batch)
+            torch.cuda.synchronize()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            for _ in range(3):
+                plan6.keyswitch(r6, t6, a.batch)
+            f1.record()
+            torch.cuda.synchronize()
+            ms6 = f0.elapsed_time(f1) / 3
+            extra["keyswitch_16384_6_7_7_2"] = {"keyswitches_per_s": a.batch / (ms6 * 1e-3),
+                                                "alg_GBps": ks_alg_bytes(N, 6) * a.batch / (ms6 * 1e-3) / 1e9}
+            plan6.close()
+        out["extra"] = extra
+        if not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(orc_mod, case)
+        print(json.dumps(out))
+    plan.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

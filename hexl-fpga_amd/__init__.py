@@ -37,6 +37,7 @@ C_ABI = {
     "hexl_ctx_create": [_i, ctypes.POINTER(_vp)],
     "hexl_ctx_destroy": [_vp],
     "hexl_ctx_set_stream": [_vp, _vp],
+    "hexl_ctx_use_own_stream": [_vp],
     "hexl_ctx_sync": [_vp],
     "hexl_ctx_describe": [_vp, ctypes.c_char_p, _sz],
     "hexl_ntt_fwd": [_vp, _vp, _sz, _vp, _vp, _u64, _u64],
@@ -79,6 +80,9 @@ def lib() -> ctypes.CDLL:
         if not LIB_PATH.exists():
             raise HexlError(f"{LIB_PATH} missing: run __graft_entry__.build() / make -C hexl-fpga_amd/csrc "
                             "(there is no CPU fallback)")
+        # torch must load its HIP runtime first so this library binds to the SAME libamdhip64 instance
+        # (device pointers from torch tensors are only meaningful inside one runtime).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(str(LIB_PATH))
         for name, args in C_ABI.items():
             fn = getattr(_lib, name)

@@ -55,7 +55,12 @@ extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
 
 extern "C" int hexl_ctx_set_stream(hexl_ctx* c, void* s) {
     if (!c) return HEXL_E_BADARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;
+    return 0;
+}
+extern "C" int hexl_ctx_use_own_stream(hexl_ctx* c) {
+    if (!c) return HEXL_E_BADARG;
+    c->stream = c->own_stream;
     return 0;
 }
 extern "C" int hexl_ctx_sync(hexl_ctx* c) {

@@ -72,7 +72,8 @@ class HexlFpga:
 
     def _flush_dyadic(self):
         from . import lib, _check
-        q, self._q["dyadic"] = self._q["dyadic"], []
+        q = list(self._q["dyadic"])
+        self._q["dyadic"].clear()      # in place: callers hold a reference to the live queue
         if not q:
             return
         ctx = self._need()
@@ -108,7 +109,8 @@ class HexlFpga:
 
     def _flush_ntt(self):
         from . import lib, _check
-        q, self._q["ntt"] = self._q["ntt"], []
+        q = list(self._q["ntt"])
+        self._q["ntt"].clear()      # in place: callers hold a reference to the live queue
         if not q:
             return
         ctx = self._need()
@@ -143,7 +145,8 @@ class HexlFpga:
 
     def _flush_intt(self):
         from . import lib, _check
-        q, self._q["intt"] = self._q["intt"], []
+        q = list(self._q["intt"])
+        self._q["intt"].clear()      # in place: callers hold a reference to the live queue
         if not q:
             return
         ctx = self._need()
@@ -188,7 +191,8 @@ class HexlFpga:
 
     def _flush_ks(self):
         from . import KeySwitchPlan
-        q, self._q["ks"] = self._q["ks"], []
+        q = list(self._q["ks"])
+        self._q["ks"].clear()      # in place: callers hold a reference to the live queue
         if not q:
             return
         ctx = self._need()

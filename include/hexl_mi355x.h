@@ -35,8 +35,10 @@ typedef struct hexl_ks_plan hexl_ks_plan; /* keyswitch parameter set: tables + k
  * binds `device`, creates the stream. */
 int hexl_ctx_create(int device, hexl_ctx** out);
 int hexl_ctx_destroy(hexl_ctx* ctx);
-/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own one */
+/* run on a caller-owned hipStream_t (e.g. torch's current stream; NULL = the legacy default stream) */
 int hexl_ctx_set_stream(hexl_ctx* ctx, void* hip_stream);
+/* go back to the context's own non-blocking stream (the state after hexl_ctx_create) */
+int hexl_ctx_use_own_stream(hexl_ctx* ctx);
 int hexl_ctx_sync(hexl_ctx* ctx);
 /* library/device report for logs: writes a NUL-terminated string */
 int hexl_ctx_describe(hexl_ctx* ctx, char* buf, size_t buflen);

@@ -40,8 +40,8 @@ def test_caller_twiddles_honoured(hx, ctx, dev, orc):
     assert np.array_equal(got[0], case.expected(orc, t, r))
 
 
-def test_batch_chunks_and_linearity(hx, ctx, dev, orc, monkeypatch):
-    """batch larger than one scratch chunk; keyswitch is linear in t_target and additive in result"""
+def test_batch_chunks_and_accumulate(hx, ctx, dev, orc):
+    """batch larger than one scratch chunk; the output is accumulated into result"""
     n, L, K = 16384, 6, 7
     case = KsCase(orc, n, L, K, seed=5)
     plan = hx.KeySwitchPlan(ctx, n, L, K, L + 1, 2, case.moduli, case.modswitch)
@@ -60,15 +60,14 @@ def test_batch_chunks_and_linearity(hx, ctx, dev, orc, monkeypatch):
     assert np.array_equal(out[0], e0) and np.array_equal(out[1], e1)
     assert np.array_equal(out[298], e0) and np.array_equal(out[299], e1)
     assert (out[0::2] == e0).all() and (out[1::2] == e1).all()
-    # linearity: KS(t0 + t1) == KS(t0) + KS(t1) (mod q_i per limb), accumulate: second call adds again
-    qs = np.repeat(case.moduli[:L].astype(object), n)
-    tsum = ((t0.astype(object) + t1.astype(object)) % qs).astype(np.uint64)
-    d_t2, d_r2 = hx.as_i64(tsum).to(dev), hx.as_i64(np.zeros_like(r0)).to(dev)
+    # additivity in `result` (fpga.cpp:441-475 accumulates): KS(t, r) == r + KS(t, 0) mod q_i, and calling
+    # twice adds twice. (KS is NOT linear in t: the special-prime division rounds, intt2_redu.hpp:25-51.)
+    qs = np.tile(np.repeat(case.moduli[:L].astype(object), n), 2)
+    d_t2, d_r2 = hx.as_i64(t0).to(dev), hx.as_i64(r0).to(dev)
     plan.keyswitch(d_r2, d_t2, 1)
     ctx.sync()
-    q2 = np.tile(qs, 2)
-    assert np.array_equal(hx.to_u64(d_r2).astype(object), (e0.astype(object) + e1.astype(object)) % q2)
+    assert np.array_equal(hx.to_u64(d_r2).astype(object), (r0.astype(object) + e0.astype(object)) % qs)
     plan.keyswitch(d_r2, d_t2, 1)
     ctx.sync()
-    assert np.array_equal(hx.to_u64(d_r2).astype(object), (2 * (e0.astype(object) + e1.astype(object))) % q2)
+    assert np.array_equal(hx.to_u64(d_r2).astype(object), (r0.astype(object) + 2 * e0.astype(object)) % qs)
     plan.close()

@@ -23,14 +23,14 @@ def run_fwd(hx, ctx, dev, x, t):
     d = _dev(hx, x, dev)
     ctx.ntt_fwd(d, _dev(hx, t.roots, dev), _dev(hx, t.precon, dev), t.q, t.n)
     ctx.sync()
-    return hx.to_u64(d)
+    return hx.to_u64(d).reshape(-1, t.n)
 
 
 def run_inv(hx, ctx, dev, x, t):
     d = _dev(hx, x, dev)
     ctx.ntt_inv(d, _dev(hx, t.inv_roots, dev), _dev(hx, t.inv_precon, dev), t.q, t.inv_n, t.inv_n_w, t.n)
     ctx.sync()
-    return hx.to_u64(d)
+    return hx.to_u64(d).reshape(-1, t.n)
 
 
 @pytest.mark.parametrize("bits", [20, 32, 55, 62])
@@ -39,11 +39,11 @@ def test_fwd_inv_reference_matrix(hx, ctx, dev, orc, bits):
     q = orc.primes(1, bits, n)[0]
     t = orc.HexlTables(n, q)
     x = np.stack([stimulus(k, n, q) for k in STIMS])
-    got = run_fwd(hx, ctx, dev, x, t).reshape(len(STIMS), n)
+    got = run_fwd(hx, ctx, dev, x, t)
     exp = orc.ntt_fwd(x, t)
     for k, name in enumerate(STIMS):
         assert np.array_equal(got[k], exp[k]), f"fwd {bits}-bit {name}"
-    got = run_inv(hx, ctx, dev, x, t).reshape(len(STIMS), n)
+    got = run_inv(hx, ctx, dev, x, t)
     exp = orc.ntt_inv(x, t)
     for k, name in enumerate(STIMS):
         assert np.array_equal(got[k], exp[k]), f"inv {bits}-bit {name}"
@@ -58,10 +58,10 @@ def test_golden_digests(hx, ctx, dev, orc, rec):
     for name, s in rec["stimuli"].items():
         x = {"RAMP": np.arange(n, dtype=np.uint64), "ALLMAX": np.full(n, 2**64 - 1, dtype=np.uint64),
              "SPLITMIX42": orc.splitmix(n, 42, q)}[name]
-        f = run_fwd(hx, ctx, dev, x, t)
+        f = run_fwd(hx, ctx, dev, x, t)[0]
         assert "%016x" % orc.fnv(f) == s["fwd_fnv"], f"fwd {name}"
         assert [int(v) for v in f[:4]] == s["fwd_head"] and [int(v) for v in f[-4:]] == s["fwd_tail"]
-        i = run_inv(hx, ctx, dev, x, t)
+        i = run_inv(hx, ctx, dev, x, t)[0]
         assert "%016x" % orc.fnv(i) == s["inv_fnv"], f"inv {name}"
         assert [int(v) for v in i[:4]] == s["inv_head"] and [int(v) for v in i[-4:]] == s["inv_tail"]
 
@@ -71,8 +71,8 @@ def test_all_sizes_random(hx, ctx, dev, orc, n):
     q = orc.primes(2, 51, n)[1]
     t = orc.HexlTables(n, q)
     x = np.stack([orc.splitmix(n, 100 + b, q) for b in range(5)])
-    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t).ravel())
-    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t).ravel())
+    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t))
+    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t))
 
 
 def test_random_tables_like_benchmark(hx, ctx, dev, orc):
@@ -84,9 +84,9 @@ def test_random_tables_like_benchmark(hx, ctx, dev, orc):
     for arr in (t.roots, t.precon, t.inv_roots, t.inv_precon):
         arr[:] = rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)
     x = rng.integers(0, 2**64 - 1, size=(3, n), dtype=np.uint64)
-    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t).ravel())
+    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t))
     t.inv_n, t.inv_n_w = int(rng.integers(0, q)), int(rng.integers(0, q))
-    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t).ravel())
+    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t))
 
 
 def test_full_batch_roundtrip_and_linearity(hx, ctx, dev, orc):
@@ -105,8 +105,8 @@ def test_full_batch_roundtrip_and_linearity(hx, ctx, dev, orc):
     assert int(f.max()) < q
     # linearity: NTT(a) + NTT(b) == NTT(a + b) mod q
     s = (x[0].astype(object) + x[1].astype(object)) % q
-    fs = run_fwd(hx, ctx, dev, np.array(s, dtype=np.uint64), t)
+    fs = run_fwd(hx, ctx, dev, np.array(s, dtype=np.uint64), t)[0]
     assert np.array_equal((f[0].astype(object) + f[1].astype(object)) % q, fs.astype(object))
     ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
     ctx.sync()
-    assert torch.equal(d.cpu(), hx.as_i64(x).reshape(-1))
+    assert torch.equal(d.cpu().reshape(-1), hx.as_i64(x).reshape(-1))
