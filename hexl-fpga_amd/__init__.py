@@ -48,9 +48,10 @@ C_ABI = {
     "hexl_ks_set_keys": [_vp, ctypes.POINTER(_vp)],
     "hexl_keyswitch": [_vp, _vp, _vp, _sz],
     "hexl_ks_scratch_bytes": [_vp, _sz],
-    "hexl_ntt_fwd_host": [_vp, _vp, _sz, _vp, _vp, _u64, _u64],
-    "hexl_ntt_inv_host": [_vp, _vp, _sz, _vp, _vp, _u64, _u64, _u64, _u64],
-    "hexl_dyadic_multiply_host": [_vp, _vp, _vp, _vp, _sz, _u64, _vp, _u64],
+    "hexl_ntt_fwd_host": [_vp, ctypes.POINTER(_vp), _sz, _vp, _vp, _u64, _u64],
+    "hexl_ntt_inv_host": [_vp, ctypes.POINTER(_vp), _sz, _vp, _vp, _u64, _u64, _u64, _u64],
+    "hexl_dyadic_multiply_host": [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _sz, _u64,
+                                  ctypes.POINTER(_vp), _u64],
     "hexl_keyswitch_host": [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _sz],
     "hexl_ks_time_stages": [_vp, _vp, _vp, _sz, _i, ctypes.POINTER(ctypes.c_float)],
 }
@@ -94,6 +95,11 @@ def lib() -> ctypes.CDLL:
 def _check(rc: int, what: str):
     if rc != 0:
         raise HexlError(f"{what} failed with status {rc}")
+
+
+def ptr_array(arrays):
+    """ctypes array of host pointers to numpy arrays (kept alive by the caller)"""
+    return (_vp * len(arrays))(*[a.ctypes.data for a in arrays])
 
 
 def _ptr(t) -> int:

@@ -254,59 +254,70 @@ static int stage_reserve(hexl_ctx* c, size_t bytes) {
     return hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, bytes);
 }
 
-extern "C" int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* h_x, size_t batch, const uint64_t* h_roots,
+extern "C" int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch, const uint64_t* h_roots,
                                  const uint64_t* h_precon, uint64_t q, uint64_t n) {
     if (!c || !h_x || !h_roots || !h_precon || !supported_ntt_n(n)) return HEXL_E_BADARG;
+    if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t data = batch * n * 8, tab = n * 8;
+    const size_t one = n * 8, data = batch * one, tab = one;
     int rc = stage_reserve(c, data + 2 * tab);
     if (rc) return rc;
     char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    memcpy(h, h_roots, tab); memcpy(h + tab, h_precon, tab); memcpy(h + 2 * tab, h_x, data);
+    memcpy(h, h_roots, tab); memcpy(h + tab, h_precon, tab);
+    for (size_t b = 0; b < batch; ++b) memcpy(h + 2 * tab + b * one, h_x[b], one);
     HX_CHECK(hipMemcpyAsync(d, h, data + 2 * tab, hipMemcpyHostToDevice, c->stream));
     rc = hexl_ntt_fwd(c, (u64*)(d + 2 * tab), batch, (u64*)d, (u64*)(d + tab), q, n);
     if (rc) return rc;
     HX_CHECK(hipMemcpyAsync(h + 2 * tab, d + 2 * tab, data, hipMemcpyDeviceToHost, c->stream));
     HX_CHECK(hipStreamSynchronize(c->stream));
-    memcpy(h_x, h + 2 * tab, data);
+    for (size_t b = 0; b < batch; ++b) memcpy(h_x[b], h + 2 * tab + b * one, one);
     return 0;
 }
 
-extern "C" int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* h_x, size_t batch, const uint64_t* h_ir, const uint64_t* h_ip,
-                                 uint64_t q, uint64_t inv_n, uint64_t inv_n_w, uint64_t n) {
+extern "C" int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch, const uint64_t* h_ir,
+                                 const uint64_t* h_ip, uint64_t q, uint64_t inv_n, uint64_t inv_n_w, uint64_t n) {
     if (!c || !h_x || !h_ir || !h_ip || !supported_ntt_n(n)) return HEXL_E_BADARG;
+    if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t data = batch * n * 8, tab = n * 8;
+    const size_t one = n * 8, data = batch * one, tab = one;
     int rc = stage_reserve(c, data + 2 * tab);
     if (rc) return rc;
     char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    memcpy(h, h_ir, tab); memcpy(h + tab, h_ip, tab); memcpy(h + 2 * tab, h_x, data);
+    memcpy(h, h_ir, tab); memcpy(h + tab, h_ip, tab);
+    for (size_t b = 0; b < batch; ++b) memcpy(h + 2 * tab + b * one, h_x[b], one);
     HX_CHECK(hipMemcpyAsync(d, h, data + 2 * tab, hipMemcpyHostToDevice, c->stream));
     rc = hexl_ntt_inv(c, (u64*)(d + 2 * tab), batch, (u64*)d, (u64*)(d + tab), q, inv_n, inv_n_w, n);
     if (rc) return rc;
     HX_CHECK(hipMemcpyAsync(h + 2 * tab, d + 2 * tab, data, hipMemcpyDeviceToHost, c->stream));
     HX_CHECK(hipStreamSynchronize(c->stream));
-    memcpy(h_x, h + 2 * tab, data);
+    for (size_t b = 0; b < batch; ++b) memcpy(h_x[b], h + 2 * tab + b * one, one);
     return 0;
 }
 
-extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* h_out, const uint64_t* h_a, const uint64_t* h_b,
-                                         size_t batch, uint64_t n, const uint64_t* h_moduli, uint64_t n_moduli) {
+extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* h_out, const uint64_t* const* h_a,
+                                         const uint64_t* const* h_b, size_t batch, uint64_t n,
+                                         const uint64_t* const* h_moduli, uint64_t n_moduli) {
     if (!c || !h_out || !h_a || !h_b || !h_moduli) return HEXL_E_BADARG;
+    if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t in = batch * 2 * n_moduli * n * 8, outb = batch * 3 * n_moduli * n * 8, mod = batch * n_moduli * 8;
+    const size_t in1 = 2 * n_moduli * n * 8, out1 = 3 * n_moduli * n * 8, mod1 = n_moduli * 8;
+    const size_t in = batch * in1, outb = batch * out1, mod = batch * mod1;
     const size_t mod_pad = (mod + 255) & ~size_t(255);
     int rc = stage_reserve(c, 2 * in + outb + mod_pad);
     if (rc) return rc;
     char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    memcpy(h, h_moduli, mod); memcpy(h + mod_pad, h_a, in); memcpy(h + mod_pad + in, h_b, in);
+    for (size_t b = 0; b < batch; ++b) {
+        memcpy(h + b * mod1, h_moduli[b], mod1);
+        memcpy(h + mod_pad + b * in1, h_a[b], in1);
+        memcpy(h + mod_pad + in + b * in1, h_b[b], in1);
+    }
     HX_CHECK(hipMemcpyAsync(d, h, mod_pad + 2 * in, hipMemcpyHostToDevice, c->stream));
     rc = hexl_dyadic_multiply(c, (u64*)(d + mod_pad + 2 * in), (u64*)(d + mod_pad), (u64*)(d + mod_pad + in), batch, n,
                               (u64*)d, n_moduli);
     if (rc) return rc;
     HX_CHECK(hipMemcpyAsync(h + mod_pad + 2 * in, d + mod_pad + 2 * in, outb, hipMemcpyDeviceToHost, c->stream));
     HX_CHECK(hipStreamSynchronize(c->stream));
-    memcpy(h_out, h + mod_pad + 2 * in, outb);
+    for (size_t b = 0; b < batch; ++b) memcpy(h_out[b], h + mod_pad + 2 * in + b * out1, out1);
     return 0;
 }
 

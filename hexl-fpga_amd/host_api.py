@@ -77,15 +77,11 @@ class HexlFpga:
         if not q:
             return
         ctx = self._need()
+        from . import ptr_array
         n, nm = q[0][3], q[0][5]
-        a = np.concatenate([o[1][: 2 * nm * n] for o in q])
-        b = np.concatenate([o[2][: 2 * nm * n] for o in q])
-        mod = np.concatenate([o[4][:nm] for o in q])
-        out = np.empty(len(q) * 3 * nm * n, dtype=np.uint64)
-        _check(lib().hexl_dyadic_multiply_host(ctx.h, out.ctypes.data, a.ctypes.data, b.ctypes.data, len(q), n,
-                                               mod.ctypes.data, nm), "hexl_dyadic_multiply_host")
-        for k, o in enumerate(q):
-            o[0][: 3 * nm * n] = out[k * 3 * nm * n:(k + 1) * 3 * nm * n]
+        _check(lib().hexl_dyadic_multiply_host(ctx.h, ptr_array([o[0] for o in q]), ptr_array([o[1] for o in q]),
+                                               ptr_array([o[2] for o in q]), len(q), n,
+                                               ptr_array([o[4] for o in q]), nm), "hexl_dyadic_multiply_host")
 
     # ---- _NTT / _INTT (host/src/ntt.cpp:15-28, intt.cpp:15-29) ----
     def _set_worksize_NTT(self, ws: int):
@@ -115,11 +111,9 @@ class HexlFpga:
             return
         ctx = self._need()
         _, roots, precon, mod, n = q[0]                       # tables of the first object (fpga.cpp:403-411)
-        x = np.concatenate([o[0][:n] for o in q])
-        _check(lib().hexl_ntt_fwd_host(ctx.h, x.ctypes.data, len(q), roots.ctypes.data, precon.ctypes.data, mod, n),
-               "hexl_ntt_fwd_host")
-        for k, o in enumerate(q):
-            o[0][:n] = x[k * n:(k + 1) * n]
+        from . import ptr_array
+        _check(lib().hexl_ntt_fwd_host(ctx.h, ptr_array([o[0] for o in q]), len(q), roots.ctypes.data,
+                                       precon.ctypes.data, mod, n), "hexl_ntt_fwd_host")
 
     def _set_worksize_INTT(self, ws: int):
         self._ws["intt"] = int(ws)
@@ -151,11 +145,9 @@ class HexlFpga:
             return
         ctx = self._need()
         _, ir, ip, mod, inv_n, inv_n_w, n = q[0]
-        x = np.concatenate([o[0][:n] for o in q])
-        _check(lib().hexl_ntt_inv_host(ctx.h, x.ctypes.data, len(q), ir.ctypes.data, ip.ctypes.data, mod, inv_n,
-                                       inv_n_w, n), "hexl_ntt_inv_host")
-        for k, o in enumerate(q):
-            o[0][:n] = x[k * n:(k + 1) * n]
+        from . import ptr_array
+        _check(lib().hexl_ntt_inv_host(ctx.h, ptr_array([o[0] for o in q]), len(q), ir.ctypes.data, ip.ctypes.data,
+                                       mod, inv_n, inv_n_w, n), "hexl_ntt_inv_host")
 
     # ---- KeySwitch (host/src/keyswitch.cpp:15-41) ----
     def set_worksize_KeySwitch(self, ws: int):

@@ -91,24 +91,25 @@ int hexl_keyswitch(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_t
 /* bytes of HBM scratch a batch of `batch` keyswitches needs (for capacity planning) */
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* plan, size_t batch);
 
-/* Host-pointer conveniences used by the C++ API layer: pinned staging + H2D/D2H around the
- * launchers above; synchronous on return. */
-int hexl_ntt_fwd_host(hexl_ctx* ctx, uint64_t* h_x, size_t batch, const uint64_t* h_roots,
+/* Host-pointer entry points used by the C++ API layer (libhexl-fpga.so): pinned staging + H2D/D2H
+ * around the launchers above; synchronous on return. Every object is passed by its own pointer -- the
+ * reference needs batch elements contiguous for NTT/INTT/dyadic (one memcpy from the first object,
+ * host/src/fpga.cpp:379-388,405-406) and copies keyswitch objects one by one (fpga.cpp:542-555); per-object
+ * pointers are a superset of both. */
+int hexl_ntt_fwd_host(hexl_ctx* ctx, uint64_t* const* h_x, size_t batch, const uint64_t* h_roots,
                       const uint64_t* h_precon, uint64_t q, uint64_t n);
-int hexl_ntt_inv_host(hexl_ctx* ctx, uint64_t* h_x, size_t batch, const uint64_t* h_inv_roots,
+int hexl_ntt_inv_host(hexl_ctx* ctx, uint64_t* const* h_x, size_t batch, const uint64_t* h_inv_roots,
                       const uint64_t* h_inv_precon, uint64_t q, uint64_t inv_n,
                       uint64_t inv_n_w, uint64_t n);
-int hexl_dyadic_multiply_host(hexl_ctx* ctx, uint64_t* h_out, const uint64_t* h_a,
-                              const uint64_t* h_b, size_t batch, uint64_t n,
-                              const uint64_t* h_moduli, uint64_t n_moduli);
-/* per-object pointers (the reference copies each object separately, fpga.cpp:542-555) */
+int hexl_dyadic_multiply_host(hexl_ctx* ctx, uint64_t* const* h_out, const uint64_t* const* h_a,
+                              const uint64_t* const* h_b, size_t batch, uint64_t n,
+                              const uint64_t* const* h_moduli, uint64_t n_moduli);
 int hexl_keyswitch_host(hexl_ks_plan* plan, uint64_t* const* h_results,
                         const uint64_t* const* h_t_targets, size_t batch);
 
-/* timing hook for bench.py: average milliseconds per launch of the named kernel group over
- * `iters` launches, measured with hipEvents on the context's stream.
- *   which: 0 fwd NTT, 1 inv NTT, 2 dyadic, 3 keyswitch (whole pipeline),
- *          4..6 keyswitch stage kernels ks_intt / ks_modup_mac / ks_moddown */
+/* timing hook for bench.py: average milliseconds per keyswitch launch and per stage kernel
+ * (ks_intt / ks_modup / ks_moddown) over `iters` launches of a batch that fits one scratch chunk,
+ * measured with hipEvents on the context's stream. */
 int hexl_ks_time_stages(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_target,
                         size_t batch, int iters, float* ms_out /* [4]: total, s1, s2, s3 */);
 
