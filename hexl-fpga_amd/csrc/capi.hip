@@ -1,5 +1,6 @@
 // capi.hip -- the extern "C" launcher ABI of include/hexl_mi355x.h: contexts, keyswitch plans
 // (host precompute + upload), host-pointer staging variants, and the hipEvent timing hook.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -101,10 +102,19 @@ extern "C" int hexl_dyadic_multiply(hexl_ctx* c, uint64_t* out, const uint64_t* 
 }
 
 // ------------------------------------------------------------------------------- K4 plan
-static u32 ks_loge(u32 logn) { return logn <= 10 ? 4 : 5; }
-static u32 ks_idxB(u32 logn, u32 r, u32 tid) {
-    const u32 loge = ks_loge(logn), P = (logn + loge - 1) / loge, KL = logn - (P - 1) * loge;
+// elements-per-thread exponent of the keyswitch kernels (must match run_chunk<> / run_chunk_f64<> dispatch)
+static u32 ks_loge(u32 logn, bool f64) { return logn <= 10 ? 4 : (f64 && logn == 14 ? 4 : 5); }
+static u32 ks_idxB(u32 logn, u32 loge, u32 r, u32 tid) {
+    const u32 P = (logn + loge - 1) / loge, KL = logn - (P - 1) * loge;
     return ((r >> KL) << (logn - loge + KL)) + (tid << KL) + (r & ((1u << KL) - 1));
+}
+// perm[pos] = natural coefficient index stored at position pos of a "B order" ([r][tid]) limb
+static std::vector<u32> ks_perm(u32 logn, u32 loge) {
+    const u32 n = 1u << logn, E = 1u << loge, T = n >> loge;
+    std::vector<u32> perm(n);
+    for (u32 r = 0; r < E; ++r)
+        for (u32 t = 0; t < T; ++t) perm[r * T + t] = ks_idxB(logn, loge, r, t);
+    return perm;
 }
 
 extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t K, uint64_t rns, uint64_t kcc,
@@ -169,6 +179,37 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         m.len = fl - 1;
         m.barr_lo = (u64)(((u128)1 << (m.len + 64)) / q);
     }
+    // FP64 path: every modulus below 2^52 (the reference's own bound); HEXL_KS_INT=1 forces the integer kernels
+    bool f64_ok = !(getenv("HEXL_KS_INT") && atoi(getenv("HEXL_KS_INT")) == 1);
+    for (u64 i = 0; i < K; ++i) f64_ok = f64_ok && h_moduli[i] < (1ULL << 52);
+    p->use_f64 = f64_ok;
+    if (f64_ok) {
+        std::vector<KsModF64> fm(K);
+        std::vector<double> ft(size_t(K) * 4 * n);
+        for (u64 i = 0; i < K; ++i) {
+            const u64 q = h_moduli[i];
+            const double pd = (double)q;
+            auto centre = [&](u64 v) { v %= q; return v > q / 2 ? (double)v - pd : (double)v; };
+            for (int blk = 0; blk < 4; blk += 2)                   // blocks 0 / 2 hold w, blocks 1 / 3 hold fl(w/p)
+                for (u64 r = 0; r < n; ++r) {
+                    const double w = centre(tables[(i * 4 + blk) * n + r]);
+                    ft[(i * 4 + blk) * n + r] = w;
+                    ft[(i * 4 + blk + 1) * n + r] = w / pd;
+                }
+            KsModF64& f = fm[i];
+            f.m.p = pd; f.m.pinv = 1.0 / pd;
+            f.sc.n = centre(mods[i].inv_n);     f.sc.n_p = f.sc.n / pd;
+            f.sc.nw = centre(mods[i].inv_n_w);  f.sc.nw_p = f.sc.nw / pd;
+            f.msf = centre(mods[i].msf);        f.msf_p = f.msf / pd;
+            f.fix = (double)mods[i].fix;
+            f.half = (double)mods[i].half;
+        }
+        HX_CHECK(hipMalloc((void**)&p->d_mods_f64, K * sizeof(KsModF64)));
+        HX_CHECK(hipMalloc((void**)&p->d_tables_f64, ft.size() * sizeof(double)));
+        HX_CHECK(hipMalloc((void**)&p->d_keys_f64, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
+        HX_CHECK(hipMemcpy(p->d_mods_f64, fm.data(), K * sizeof(KsModF64), hipMemcpyHostToDevice));
+        HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     HX_CHECK(hipMalloc((void**)&p->d_mods, K * sizeof(KsModulus)));
     HX_CHECK(hipMalloc((void**)&p->d_tables, tables.size() * sizeof(u64)));
     HX_CHECK(hipMalloc((void**)&p->d_keys, size_t(L) * (L + 1) * 2 * n * sizeof(u64)));
@@ -186,6 +227,9 @@ extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
     if (p->d_tables) (void)hipFree(p->d_tables);
     if (p->d_keys) (void)hipFree(p->d_keys);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_mods_f64) (void)hipFree(p->d_mods_f64);
+    if (p->d_tables_f64) (void)hipFree(p->d_tables_f64);
+    if (p->d_keys_f64) (void)hipFree(p->d_keys_f64);
     delete p;
     return 0;
 }
@@ -197,24 +241,32 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     if (!p || !h_keys) return HEXL_E_BADARG;
     HX_CHECK(hipSetDevice(p->ctx->device));
     const u64 n = p->n, L = p->L, K = p->K;
-    const u32 loge = ks_loge(p->logn), E = 1u << loge, T = (u32)(n >> loge);
-    std::vector<u32> perm(n);
-    for (u32 r = 0; r < E; ++r)
-        for (u32 t = 0; t < T; ++t) perm[r * T + t] = ks_idxB(p->logn, r, t);
+    const std::vector<u32> perm = ks_perm(p->logn, ks_loge(p->logn, false));
     std::vector<u64> dev(size_t(L) * (L + 1) * 2 * n);
+    std::vector<double> devf;
+    std::vector<u32> permf;
+    if (p->use_f64) { devf.resize(dev.size()); permf = ks_perm(p->logn, ks_loge(p->logn, true)); }
     for (u64 d = 0; d < L; ++d) {
         if (!h_keys[d]) return HEXL_E_BADARG;
         for (u64 slot = 0; slot <= L; ++slot) {
             const u64 i = slot < L ? slot : K - 1;
+            const u64 q = p->moduli[i];
             for (u64 k = 0; k < 2; ++k) {
                 const u64* src = h_keys[d] + (k * K + i) * n;            // fpga.cpp:1186-1190
-                u64* dst = &dev[((d * (L + 1) + slot) * 2 + k) * n];
-                for (u64 j = 0; j < n; ++j) dst[j] = src[perm[j]];
+                const size_t base = ((d * (L + 1) + slot) * 2 + k) * n;
+                for (u64 j = 0; j < n; ++j) dev[base + j] = src[perm[j]];
+                if (p->use_f64)                                          // same limb as centred doubles
+                    for (u64 j = 0; j < n; ++j) {
+                        const u64 v = src[permf[j]] % q;
+                        devf[base + j] = v > q / 2 ? (double)v - (double)q : (double)v;
+                    }
             }
         }
     }
     HX_CHECK(hipStreamSynchronize(p->ctx->stream));
     HX_CHECK(hipMemcpy(p->d_keys, dev.data(), dev.size() * sizeof(u64), hipMemcpyHostToDevice));
+    if (p->use_f64)
+        HX_CHECK(hipMemcpy(p->d_keys_f64, devf.data(), devf.size() * sizeof(double), hipMemcpyHostToDevice));
     p->have_keys = true;
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/hexl_mi355x.h"
+#include "f64_arith.hpp"
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -50,6 +51,15 @@ struct KsModulus {
     u64 barr_lo;    // floor(2^(len+64)/q)
 };
 
+// the same constants for the FP64 path (keyswitch_f64.hip); residues centred, *_p = fl(value / p)
+struct KsModF64 {
+    hxf::Mod m;
+    hxf::InvScale sc;
+    double msf, msf_p;   // modswitch factor
+    double fix;          // q - (floor(q_sp/2) mod q), in [1, q]
+    double half;         // floor(q_sp/2)
+};
+
 struct hexl_ks_plan {
     hexl_ctx* ctx = nullptr;
     u32 n = 0, logn = 0, L = 0, K = 0, rns = 0;
@@ -58,6 +68,11 @@ struct hexl_ks_plan {
     u64* d_tables = nullptr;          // [K][4][n]: roots, precon, inv_roots(HEXL idx), inv_precon
     u64* d_keys = nullptr;            // [L][L+1][2][n] in forward-output ("B") order
     bool have_keys = false;
+    // FP64 path (all moduli < 2^52): same tables / keys as centred doubles
+    bool use_f64 = false;
+    KsModF64* d_mods_f64 = nullptr;   // [K]
+    double* d_tables_f64 = nullptr;   // [K][4][n]
+    double* d_keys_f64 = nullptr;     // [L][L+1][2][n]
     // scratch for `cap` keyswitches in flight: c[cap][L][n], prod[cap][2][L][n], s[cap][2][n]
     u64* d_scratch = nullptr;
     size_t cap = 0;
@@ -71,6 +86,9 @@ int hx_launch_dyadic(hexl_ctx*, u64* d_out, const u64* d_a, const u64* d_b, size
                      const u64* d_moduli, u64 n_moduli);
 int hx_launch_keyswitch(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
                         hipEvent_t* ev /* optional [4] */);
+// one scratch chunk (nb <= plan->cap) on the FP64 path
+int hx_launch_keyswitch_f64(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
+                            hipEvent_t* ev);
 // index of coefficient held in register r of thread tid after a forward transform ("B layout")
 u32 hx_idxB(u32 logn, u32 r, u32 tid);
 u32 hx_loge_for(u32 logn);

@@ -201,9 +201,13 @@ static size_t ks_chunk_default() {
     return (size_t)v;
 }
 
+size_t hx_ks_f64_scratch_words(size_t L);
+static size_t scratch_words(const hexl_ks_plan* p) {           // per instance, in units of n 64-bit words
+    return p->use_f64 ? hx_ks_f64_scratch_words(p->L) : size_t(3) * p->L + 2;
+}
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
     const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
-    return chunk * (size_t(3) * p->L + 2) * p->n * sizeof(u64);
+    return chunk * scratch_words(p) * p->n * sizeof(u64);
 }
 
 int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
@@ -214,7 +218,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     if (p->cap < chunk) {
         if (p->d_scratch) HX_CHECK(hipFree(p->d_scratch));
         p->d_scratch = nullptr; p->cap = 0;
-        HX_CHECK(hipMalloc((void**)&p->d_scratch, chunk * (size_t(3) * p->L + 2) * p->n * sizeof(u64)));
+        HX_CHECK(hipMalloc((void**)&p->d_scratch, chunk * scratch_words(p) * p->n * sizeof(u64)));
         p->cap = chunk;
     }
     const size_t n = p->n, L = p->L;
@@ -229,6 +233,11 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         a.result = d_result + b0 * 2 * L * n;
         a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
         int rc;
+        if (p->use_f64) {
+            rc = hx_launch_keyswitch_f64(p, d_result + b0 * 2 * L * n, d_t_target + b0 * L * n, nb, stage_mask, ev);
+            if (rc) return rc;
+            continue;
+        }
         switch (p->logn) {
             case 10: rc = run_chunk<10, 4>(p, a, stage_mask, ev); break;
             case 11: rc = run_chunk<11, 5>(p, a, stage_mask, ev); break;

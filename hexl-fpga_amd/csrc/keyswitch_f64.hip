@@ -1,0 +1,243 @@
+// keyswitch_f64.hip -- K4 on the FP64 pipe: the production keyswitch path when every modulus is < 2^52
+// (the reference's own limit, host/src/keyswitch.cpp:32). Same three fused kernels and dataflow as
+// keyswitch.hip; arithmetic from f64_arith.hpp (exact integers in doubles), so
+// results are bit-identical to the integer path and to the reference's canonical pipeline.
+//
+// HBM-resident intermediates are doubles: c (canonical, natural order), prod (centred, natural order),
+// s' (canonical, natural order), keys and twiddles (centred; keys in the mod-up kernel's register order).
+// Only t_target (read) and result (read-modify-write) are converted from/to uint64.
+#include <stdlib.h>
+
+#include "hexl_internal.hpp"
+#include "ntt_core_f64.hpp"
+
+using namespace hx;
+
+struct KsArgsF {
+    const KsModF64* mods;    // [K]
+    const double* tables;    // [K][4][n]: w, w/p, inverse w (first entry at index 1), inverse w/p
+    const double* keys;      // [L][L+1][2][n] centred, B order
+    double* c;               // [chunk][L][n]          canonical, natural order
+    double* u;               // [chunk][L+1][L][n]     centred, B order
+    double* prod;            // [chunk][2][L+1][n]     centred, B order
+    double* s;               // [chunk][2][n]          canonical, natural order
+    const u64* t_target;     // [chunk][L][n]
+    u64* result;             // [chunk][2][L][n]
+    u32 L, K, nb;
+};
+
+__device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswitch.hip: XCD-contiguous work ranges
+    const u32 q = total >> 3, r = total & 7, xcd = bid & 7, j = bid >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+// step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 item = blockIdx.x;                                  // b*L + d
+    const u32 d = __builtin_amdgcn_readfirstlane(item % a.L);
+    const KsModF64 md = a.mods[d];
+    const double* tb = a.tables + size_t(d) * 4 * G::N;
+    const u64* src = a.t_target + size_t(item) * G::N;
+    double v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), md.m);
+    WgNttF64<LOGN, LOGE>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    double* dst = a.c + size_t(item) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = hxf::lift(v[r], md.m);
+}
+
+// step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i), one transform per workgroup, kept in the forward
+// transform's register order ("B order", fully coalesced). slot == d needs no transform: c_d = INTT(t_d) and
+// the moduli agree, so u = t_target[d] (the reference recomputes it; the value is identical for in-range data).
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = xcd_item_f(blockIdx.x, gridDim.x);           // (slot*L + d)*nb + b : one XCD works on one (slot, d)
+    const u32 sd = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - sd * a.nb;
+    const u32 slot = sd / L, d = sd - slot * L;
+    const u32 i = slot < L ? slot : a.K - 1;
+    const KsModF64 md = a.mods[i];
+    const Mod m = md.m;
+    double* dst = a.u + ((size_t(b) * (L + 1) + slot) * L + d) * G::N;
+    double v[G::E];
+    if (slot == d) {
+        const u64* src = a.t_target + (size_t(b) * L + d) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), m);
+        return;
+    }
+    const double* cd = a.c + (size_t(b) * L + d) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(cd[G::idxA(r, tid)], m);          // c_d mod q_i (intt1_redu.hpp:36-42)
+    const double* tb = a.tables + size_t(i) * 4 * G::N;
+    W::forward(v, ldsd, tid, tb, tb + G::N, m);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = v[r];
+}
+
+// step 3: prod[b][k][slot] = sum_d u[b][slot][d] . key[d][k][slot]  (dyadmult.hpp:128-140). Pure streaming:
+// a thread owns two adjacent coefficients of one slot, keeps their 2*L*2 key words in registers and walks the
+// batch, so keys are read once per launch and u / prod exactly once.
+template <int MAXL>
+__global__ __launch_bounds__(256) void k_ksf_mac(KsArgsF a, u32 n) {
+    const u32 L = a.L;
+    const u32 pairs = n >> 1;
+    const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;        // (slot, pair)
+    const u32 slot = gid / pairs;
+    if (slot > L) return;
+    const u32 j = (gid - slot * pairs) * 2;
+    const u32 i = slot < L ? slot : a.K - 1;
+    const Mod m = a.mods[i].m;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 key[MAXL][2];
+#pragma unroll
+    for (int d = 0; d < MAXL; ++d)
+        if (d < (int)L) {
+            key[d][0] = *reinterpret_cast<const d2*>(a.keys + ((size_t(d) * (L + 1) + slot) * 2 + 0) * n + j);
+            key[d][1] = *reinterpret_cast<const d2*>(a.keys + ((size_t(d) * (L + 1) + slot) * 2 + 1) * n + j);
+        }
+    for (u32 b = blockIdx.y; b < a.nb; b += gridDim.y) {
+        const double* ub = a.u + ((size_t(b) * (L + 1) + slot) * L) * n + j;
+        d2 acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < MAXL; ++d)
+            if (d < (int)L) {
+                const d2 u = *reinterpret_cast<const d2*>(ub + size_t(d) * n);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc0[e] = hxf::reduce(acc0[e] + hxf::mul_mod(u[e], key[d][0][e], m), m);
+                    acc1[e] = hxf::reduce(acc1[e] + hxf::mul_mod(u[e], key[d][1][e], m), m);
+                }
+            }
+        *reinterpret_cast<d2*>(a.prod + ((size_t(b) * 2 + 0) * (L + 1) + slot) * n + j) = acc0;
+        *reinterpret_cast<d2*>(a.prod + ((size_t(b) * 2 + 1) * (L + 1) + slot) * n + j) = acc1;
+    }
+}
+
+// step 4: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2)  (mod q_sp), canonical
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = blockIdx.x;                                  // b*2 + k
+    const u32 i = a.K - 1;
+    const KsModF64 md = a.mods[i];
+    const Mod m = md.m;
+    const double* tb = a.tables + size_t(i) * 4 * G::N;
+    const double* src = a.prod + (size_t(item) * (L + 1) + L) * G::N;
+    double v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = src[r * G::T + tid];
+    WgNttF64<LOGN, LOGE>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
+    double* dst = a.s + size_t(item) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r)                                // intt2_redu.hpp:25,43
+        dst[G::idxA(r, tid)] = hxf::lift(hxf::reduce(hxf::lift(v[r], m) + md.half, m), m);
+}
+
+// steps 5-7: w = NTT((s' + fix_i) mod q_i); result += (prod - w) * msf_i
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = xcd_item_f(blockIdx.x, gridDim.x);           // (i*2 + k)*nb + b
+    const u32 ik = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - ik * a.nb;
+    const u32 i = ik >> 1, k = ik & 1;
+    const KsModF64 md = a.mods[i];
+    const Mod m = md.m;
+    const double* tb = a.tables + size_t(i) * 4 * G::N;
+
+    const double* sk = a.s + (size_t(b) * 2 + k) * G::N;
+    double v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(sk[G::idxA(r, tid)] + md.fix, m);   // intt2_redu.hpp:49-51
+    W::forward(v, ldsd, tid, tb, tb + G::N, m);
+
+    const double* pk = a.prod + ((size_t(b) * 2 + k) * (L + 1) + i) * G::N;
+    u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const int idx = G::idxB(r, tid);
+        const double in = pk[r * G::T + tid] - v[r];                                   // ms.hpp:70-78
+        const double out = hxf::mul_shoup(in, md.msf, md.msf_p, m);                    // ms.hpp:80-82
+        const double rr = hxf::reduce(hxf::to_f64(res[idx]) + out, m);                 // fpga.cpp:453-457
+        res[idx] = hxf::from_f64(hxf::lift(rr, m));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class K>
+static int set_lds(K kern, size_t bytes) {
+    HX_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <int LOGN, int LOGE>
+static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipEvent_t* ev) {
+    using G = Geom<LOGN, LOGE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = set_lds(k_ksf_intt<LOGN, LOGE>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE>, G::LDS_BYTES);
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipStream_t st = p->ctx->stream;
+    const u32 L = a.L, nb = a.nb;
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1)
+        hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (stage_mask & 2) {
+        hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE>), dim3(nb * (L + 1) * L), dim3(G::T), G::LDS_BYTES, st, a);
+        const u32 threads = (L + 1) * (G::N / 2);
+        const u32 by = nb < 8 ? nb : 8;                            // 8 batch lanes keep >= 2048 workgroups in flight
+        if (L <= 8) hipLaunchKernelGGL((k_ksf_mac<8>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);
+        else        hipLaunchKernelGGL((k_ksf_mac<16>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);
+        hipLaunchKernelGGL((k_ksf_intt_sp<LOGN, LOGE>), dim3(nb * 2), dim3(G::T), G::LDS_BYTES, st, a);
+    }
+    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
+    if (stage_mask & 4)
+        hipLaunchKernelGGL((k_ksf_moddown<LOGN, LOGE>), dim3(nb * L * 2), dim3(G::T), G::LDS_BYTES, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[3], st));
+    return (int)hipGetLastError();
+}
+
+size_t hx_ks_f64_scratch_words(size_t L) { return L + (L + 1) * L + 2 * (L + 1) + 2; }   // per instance, in units of n
+
+int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
+                            hipEvent_t* ev) {
+    const size_t n = p->n, L = p->L;
+    KsArgsF a;
+    a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_f64;
+    a.c = (double*)p->d_scratch;
+    a.u = a.c + p->cap * L * n;
+    a.prod = a.u + p->cap * (L + 1) * L * n;
+    a.s = a.prod + p->cap * 2 * (L + 1) * n;
+    a.t_target = d_t_target; a.result = d_result;
+    a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    switch (p->logn) {
+        case 10: return run_chunk_f64<10, 4>(p, a, stage_mask, ev);
+        case 11: return run_chunk_f64<11, 5>(p, a, stage_mask, ev);
+        case 12: return run_chunk_f64<12, 5>(p, a, stage_mask, ev);
+        case 13: return run_chunk_f64<13, 5>(p, a, stage_mask, ev);
+        case 14: return run_chunk_f64<14, 4>(p, a, stage_mask, ev);
+        default: return HEXL_E_BADARG;
+    }
+}

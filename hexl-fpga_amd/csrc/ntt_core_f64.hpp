@@ -1,0 +1,148 @@
+// ntt_core_f64.hpp -- workgroup-level negacyclic NTT / INTT on the FP64 pipe (exact, moduli < 2^52).
+// Same register-pass / LDS re-deal structure and index maps as ntt_core.hpp (Geom, A/B layouts); only the
+// butterflies differ (f64_arith.hpp). Values are centred residues in doubles. Canonical transforms:
+//   forward : device/keyswitch/ntt_core.hpp:68-386   (twiddle index m+i, :222)
+//   inverse : device/keyswitch/intt_core.hpp:103-448 + _intt_normalize :72-93 (n^-1 folded into the last
+//             stage here, as the standalone inverse kernel does)
+#pragma once
+#include "f64_arith.hpp"
+#include "ntt_core.hpp"
+
+namespace hx {
+
+using hxf::Mod;
+
+template <int E, int OFF, int K, int S0>
+__device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
+                                               const double* __restrict__ wp, const Mod m) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const u32 base = (1u << (S0 - 1 + u)) + (G << u);
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const double W = w[base + j], Wp = wp[base + j];
+#pragma unroll
+            for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
+                const int a0 = OFF + (j << (K - u)) + c;
+                hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m);
+            }
+        }
+    }
+}
+
+using hxf::InvScale;
+
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST>
+__device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
+                                               const double* __restrict__ iwp, const Mod m, const InvScale sc) {
+    constexpr u32 N = 1u << LOGN;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool fused = LAST && (u == K - 1);
+        const u32 base = N - (N >> (LO + u)) + 1 + (G << (K - 1 - u));
+#pragma unroll
+        for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
+            double W = 0, Wp = 0;
+            if (!fused) { W = iw[base + j]; Wp = iwp[base + j]; }
+#pragma unroll
+            for (int c = 0; c < (1 << u); ++c) {
+                const int a0 = OFF + (j << (u + 1)) + c;
+                const int a1 = a0 + (1 << u);
+                if (!fused) {
+                    hxf::gs_bfly(v[a0], v[a1], W, Wp, m);
+                } else {                                   // last stage: scale both outputs by n^-1
+                    const double s = v[a0] + v[a1], d = v[a0] - v[a1];
+                    v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
+                    v[a1] = hxf::reduce(hxf::mul_shoup(d, sc.nw, sc.nw_p, m), m);
+                }
+            }
+        }
+    }
+}
+
+template <class G, class FromIdx, class ToIdx>
+__device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int tid, FromIdx from, ToIdx to) {
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) lds[G::pad(from(r, tid))] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = lds[G::pad(to(r, tid))];
+    __syncthreads();
+}
+
+template <int LOGN, int LOGE>
+struct WgNttF64 {
+    using G = Geom<LOGN, LOGE>;
+    static constexpr int E = G::E;
+
+    // forward: A layout in, B layout out, all values centred
+    template <int PASS>
+    __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
+                                                    const double* wp, const Mod m) {
+        if constexpr (PASS < G::P - 1) {
+            constexpr int LO = LOGN - (PASS + 1) * LOGE;
+            const u32 Gp = (PASS == 0) ? 0u : (u32(tid) >> LO);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1>(v, Gp, w, wp, m);
+            if constexpr (PASS + 1 < G::P - 1) {
+                constexpr int LO2 = LO - LOGE;
+                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                              [](int r, int t) { return G::template idxF<LO2>(r, t); });
+            } else {
+                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                              [](int r, int t) { return G::idxB(r, t); });
+            }
+            fwd_pass<PASS + 1>(v, lds, tid, w, wp, m);
+        } else {
+            fwd_last<0>(v, tid, w, wp, m);
+        }
+    }
+    template <int GRP>
+    __device__ static __forceinline__ void fwd_last(double (&v)[E], int tid, const double* w, const double* wp,
+                                                    const Mod m) {
+        if constexpr (GRP < G::NG) {
+            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1>(v, Gbits, w, wp, m);
+            fwd_last<GRP + 1>(v, tid, w, wp, m);
+        }
+    }
+    __device__ static __forceinline__ void forward(double (&v)[E], double* lds, int tid, const double* w,
+                                                   const double* wp, const Mod m) {
+        fwd_pass<0>(v, lds, tid, w, wp, m);
+    }
+
+    // inverse: B layout in, A layout out, centred, scaled by n^-1
+    template <int GRP>
+    __device__ static __forceinline__ void inv_first(double (&v)[E], int tid, const double* iw, const double* iwp,
+                                                     const Mod m, const InvScale sc) {
+        if constexpr (GRP < G::NG) {
+            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1)>(v, Gbits, iw, iwp, m, sc);
+            inv_first<GRP + 1>(v, tid, iw, iwp, m, sc);
+        }
+    }
+    template <int PASS>
+    __device__ static __forceinline__ void inv_pass(double (&v)[E], double* lds, int tid, const double* iw,
+                                                    const double* iwp, const Mod m, const InvScale sc) {
+        if constexpr (PASS < G::P - 1) {
+            constexpr int LO = G::KL + PASS * LOGE;
+            if constexpr (PASS == 0) {
+                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
+                              [](int r, int t) { return G::template idxF<LO>(r, t); });
+            } else {
+                constexpr int LOP = LO - LOGE;
+                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
+                              [](int r, int t) { return G::template idxF<LO>(r, t); });
+            }
+            const u32 Gp = (PASS == G::P - 2) ? 0u : (u32(tid) >> LO);
+            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iw, iwp, m, sc);
+            inv_pass<PASS + 1>(v, lds, tid, iw, iwp, m, sc);
+        }
+    }
+    __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
+                                                   const double* iwp, const Mod m, const InvScale sc) {
+        inv_first<0>(v, tid, iw, iwp, m, sc);
+        inv_pass<0>(v, lds, tid, iw, iwp, m, sc);
+    }
+};
+
+}  // namespace hx

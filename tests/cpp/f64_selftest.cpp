@@ -1,0 +1,116 @@
+// f64_selftest.cpp -- host-side validation of hexl-fpga_amd/csrc/f64_arith.hpp (the exact FP64 modular
+// arithmetic the keyswitch kernels run on gfx950). IEEE-754 double mul/add/fma/rint are correctly rounded
+// on both x86 (-mfma) and gfx950, so agreement with exact __int128 arithmetic here proves the bounds the
+// device code relies on. Checks primitives on adversarial operands, then whole transforms against the
+// oracle's canonical NTT / INTT.  Build: tests/cpp/Makefile (g++ -O2 -mfma -ffp-contract=off).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../hexl-fpga_amd/csrc/f64_arith.hpp"
+#include "../../oracle/hexl_oracle.h"
+
+typedef __int128 i128;
+static int failures = 0;
+#define CHECK(c, ...) do { if (!(c)) { if (++failures < 20) { std::printf("FAIL line %d: ", __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } } while (0)
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static int64_t centred(i128 v, int64_t p) { int64_t r = (int64_t)(v % p); if (r < 0) r += p; return r; }   // canonical actually
+
+static void test_prime(uint64_t p) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    const int64_t P = (int64_t)p;
+    std::vector<int64_t> edge = {0, 1, -1, P / 2, -(P / 2), P / 2 + 1, -(P / 2) - 1, P - 1, -(P - 1), P, -P, P + 1,
+                                 (3 * P) / 2, -(3 * P) / 2, P / 2 + 2, P / 3, 2 * P / 3};
+    auto pick = [&](int64_t bound) -> int64_t {
+        uint64_t r = rnd();
+        if ((r & 7) == 0) { int64_t e = edge[(r >> 3) % edge.size()]; if (e > bound) e = bound; if (e < -bound) e = -bound; return e; }
+        return (int64_t)(rnd() % (2 * (uint64_t)bound + 1)) - bound;
+    };
+    for (int it = 0; it < 400000; ++it) {
+        // reduce: any |x| < 2^53
+        int64_t x = pick(((int64_t)1 << 53) - 1);
+        double r = hxf::reduce((double)x, m);
+        CHECK(r == (double)(int64_t)r && (int64_t)r >= -(P / 2) - 2 && (int64_t)r <= P / 2 + 2 && centred((i128)x - (int64_t)r, P) == 0,
+              "reduce p=%lu x=%ld r=%.0f", p, x, r);
+        // lift: centred -> canonical
+        int64_t c = pick(P / 2 + 2);
+        double l = hxf::lift((double)c, m);
+        CHECK(l == (double)centred(c, P), "lift p=%lu c=%ld got %.0f", p, c, l);
+        // mul_shoup: |x| <= 1.5p, |w| <= p/2
+        int64_t xs = pick((3 * P) / 2), w = pick(P / 2);
+        double wp = (double)w / (double)p;
+        double t = hxf::mul_shoup((double)xs, (double)w, wp, m);
+        double bound = (0.5 + (double)(xs < 0 ? -xs : xs) / (2.0 * p)) * p + 1;
+        CHECK(t == (double)(int64_t)t && centred((i128)xs * w - (int64_t)t, P) == 0 && (t <= bound && t >= -bound),
+              "mul_shoup p=%lu x=%ld w=%ld t=%.0f", p, xs, w, t);
+        // mul_mod: |a|,|b| <= p/2 + 2
+        int64_t a = pick(P / 2 + 2), b = pick(P / 2 + 2);
+        double u = hxf::mul_mod((double)a, (double)b, m);
+        CHECK(u == (double)(int64_t)u && centred((i128)a * b - (int64_t)u, P) == 0 && u <= 0.7 * p + 2 && u >= -0.7 * p - 2,
+              "mul_mod p=%lu a=%ld b=%ld u=%.0f", p, a, b, u);
+        // conversions
+        uint64_t v = rnd() % p;
+        CHECK(hxf::from_f64(hxf::to_f64(v)) == v, "convert %lu", v);
+    }
+}
+
+// full transforms with the butterflies of f64_arith.hpp vs the oracle's canonical transforms
+static void test_transforms(uint64_t n, uint64_t p) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t *inv0 = blk.data(), *roots = blk.data() + 2 * n;
+    auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+    std::vector<uint64_t> x(n), ref;
+    orc_fill_splitmix(x.data(), n, p ^ n, p);
+    x[0] = p - 1; x[1] = 0; x[2] = p / 2; x[3] = p / 2 + 1;
+    // forward
+    ref = x; orc_ks_ntt(ref.data(), n, p, roots);
+    std::vector<double> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1)
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]), wp = w / (double)p;
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) hxf::ct_bfly(v[j], v[j + t], w, wp, m);
+        }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "fwd n=%lu p=%lu i=%lu", n, p, i);
+    // inverse (table from index 0, then * n^-1)
+    ref = x; orc_ks_intt(ref.data(), n, p, inv0);
+    for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
+    uint64_t acc = 0;
+    for (uint64_t mm = n >> 1, t = 1; mm >= 1; mm >>= 1, t <<= 1) {
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(inv0[acc + i]), wp = w / (double)p;
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) hxf::gs_bfly(v[j], v[j + t], w, wp, m);
+        }
+        acc += mm;
+    }
+    const double ninv = centre(orc_invmod(n, p)), ninv_p = ninv / (double)p;
+    for (uint64_t i = 0; i < n; ++i) {
+        double r = hxf::reduce(hxf::mul_shoup(v[i], ninv, ninv_p, m), m);
+        CHECK(hxf::from_f64(hxf::lift(r, m)) == ref[i], "inv n=%lu p=%lu i=%lu", n, p, i);
+    }
+}
+
+int main() {
+    std::vector<uint64_t> primes;
+    uint64_t tmp[8];
+    orc_generate_primes(tmp, 8, 51, 16384);                   // the keyswitch bench primes, just above 2^51
+    for (int i = 0; i < 8; ++i) primes.push_back(tmp[i]);
+    for (uint64_t v = (1ull << 52) - 32767; primes.size() < 11 && v > (1ull << 51); v -= 32768)   // largest < 2^52, = 1 mod 2^15
+        if (orc_is_prime(v)) primes.push_back(v);
+    orc_generate_primes(tmp, 2, 30, 16384); primes.push_back(tmp[0]);
+    orc_generate_primes(tmp, 2, 16, 1024);  primes.push_back(tmp[0]);   // ~2^16, the API's lower bound
+    orc_generate_primes(tmp, 2, 40, 16384); primes.push_back(tmp[1]);
+    for (uint64_t p : primes) test_prime(p);
+    for (uint64_t p : primes) {
+        test_transforms(1024, p);
+        if (p > (1ull << 50)) test_transforms(16384, p);
+    }
+    std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());
+    return failures ? 1 : 0;
+}
