@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define HX_HD __host__ __device__ __forceinline__
 #else
 #define HX_HD static inline __attribute__((always_inline))
@@ -87,5 +88,32 @@ HX_HD void gs_bfly(double& X, double& Y, double w, double wp, const Mod m) {
     X = reduce(s, m);
     Y = reduce(mul_shoup(d, w, wp, m), m);                   // |product| <= p before the reduce
 }
+
+// ---- lazy variants for moduli p <= 2^51 * (1 + 2^-7)  ("LAZY" regime) ------------------------------------
+// Every value only has to stay an exactly representable integer, |x| < 2^53 ~ 3.97p here, which leaves room
+// to skip most range reductions:
+//   mul_shoup bound in this regime: |x*w mod p| <= (0.5 + 0.252*|x|/p) * p   (two roundings of |x*w/p| <= |x|/2)
+//   forward:  butterflies without reduce grow the bound c (|x| <= c*p) as c -> 1.252c + 0.5:
+//             0.5 -> 1.126 -> 1.910 -> 2.891 (< 3.97); a reduce of every element after each third stage
+//             (and after the last) restarts the chain. 8 FP64 ops per butterfly + 6 every third stage.
+//   inverse:  sums double, so the sum output is reduced every stage (-> 0.5p) and the product output never:
+//             inputs <= p  =>  |X+Y|,|X-Y| <= 2p  =>  product <= (0.5 + 0.504)p ~ p: stable at c = 1. 11 ops.
+//   exactness of mul_shoup: |h - k*p| <= |result| + |l| <= 1.01p + 2^49 < 2^53.
+// tests/cpp/f64_selftest.cpp replays both schedules against exact integers and records the largest |x| seen.
+constexpr double LAZY_MAX_MODULUS = 2251799813685248.0 * (1.0 + 1.0 / 128.0);   // 2^51 * (1 + 2^-7)
+
+HX_HD void ct_bfly_lazy(double& X, double& Y, double w, double wp, const Mod m) {
+    const double t = mul_shoup(Y, w, wp, m);
+    const double a = X + t, b = X - t;
+    X = a;
+    Y = b;
+}
+HX_HD void gs_bfly_lazy(double& X, double& Y, double w, double wp, const Mod m) {
+    const double s = X + Y, d = X - Y;
+    X = reduce(s, m);
+    Y = mul_shoup(d, w, wp, m);
+}
+// forward schedule: reduce every element after global stage s (1-based) when s % 3 == 0 or s is the last stage
+HX_HD constexpr bool lazy_fwd_reduce_after(int s, int logn) { return (s % 3 == 0) || (s == logn); }
 
 }  // namespace hxf

@@ -32,7 +32,7 @@ __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswit
 }
 
 // step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles
-template <int LOGN, int LOGE>
+template <int LOGN, int LOGE, bool LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), md.m);
-    WgNttF64<LOGN, LOGE>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    WgNttF64<LOGN, LOGE, LAZY>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
     double* dst = a.c + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = hxf::lift(v[r], md.m);
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 // step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i), one transform per workgroup, kept in the forward
 // transform's register order ("B order", fully coalesced). slot == d needs no transform: c_d = INTT(t_d) and
 // the moduli agree, so u = t_target[d] (the reference recomputes it; the value is identical for in-range data).
-template <int LOGN, int LOGE>
+template <int LOGN, int LOGE, bool LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_ksf_mac(KsArgsF a, u32 n) {
 }
 
 // step 4: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2)  (mod q_sp), canonical
-template <int LOGN, int LOGE>
+template <int LOGN, int LOGE, bool LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = src[r * G::T + tid];
-    WgNttF64<LOGN, LOGE>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
+    WgNttF64<LOGN, LOGE, LAZY>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
     double* dst = a.s + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r)                                // intt2_redu.hpp:25,43
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
 }
 
 // steps 5-7: w = NTT((s' + fix_i) mod q_i); result += (prod - w) * msf_i
-template <int LOGN, int LOGE>
+template <int LOGN, int LOGE, bool LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -186,15 +186,15 @@ static int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
-template <int LOGN, int LOGE>
+template <int LOGN, int LOGE, bool LAZY>
 static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = set_lds(k_ksf_intt<LOGN, LOGE>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE>, G::LDS_BYTES);
+        int rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE, LAZY>, G::LDS_BYTES);
         if (rc) return rc;
         attr_set = true;
     }
@@ -202,19 +202,19 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     const u32 L = a.L, nb = a.nb;
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1)
-        hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2) {
-        hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE>), dim3(nb * (L + 1) * L), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * (L + 1) * L), dim3(G::T), G::LDS_BYTES, st, a);
         const u32 threads = (L + 1) * (G::N / 2);
         const u32 by = nb < 8 ? nb : 8;                            // 8 batch lanes keep >= 2048 workgroups in flight
         if (L <= 8) hipLaunchKernelGGL((k_ksf_mac<8>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);
         else        hipLaunchKernelGGL((k_ksf_mac<16>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);
-        hipLaunchKernelGGL((k_ksf_intt_sp<LOGN, LOGE>), dim3(nb * 2), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_intt_sp<LOGN, LOGE, LAZY>), dim3(nb * 2), dim3(G::T), G::LDS_BYTES, st, a);
     }
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ksf_moddown<LOGN, LOGE>), dim3(nb * L * 2), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_moddown<LOGN, LOGE, LAZY>), dim3(nb * L * 2), dim3(G::T), G::LDS_BYTES, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }
@@ -232,12 +232,22 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.s = a.prod + p->cap * 2 * (L + 1) * n;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    if (p->f64_lazy) {      // every modulus <= 2^51(1+2^-7): most range reductions are skipped (f64_arith.hpp)
+        switch (p->logn) {
+            case 10: return run_chunk_f64<10, 4, true>(p, a, stage_mask, ev);
+            case 11: return run_chunk_f64<11, 5, true>(p, a, stage_mask, ev);
+            case 12: return run_chunk_f64<12, 5, true>(p, a, stage_mask, ev);
+            case 13: return run_chunk_f64<13, 5, true>(p, a, stage_mask, ev);
+            case 14: return run_chunk_f64<14, 4, true>(p, a, stage_mask, ev);
+            default: return HEXL_E_BADARG;
+        }
+    }
     switch (p->logn) {
-        case 10: return run_chunk_f64<10, 4>(p, a, stage_mask, ev);
-        case 11: return run_chunk_f64<11, 5>(p, a, stage_mask, ev);
-        case 12: return run_chunk_f64<12, 5>(p, a, stage_mask, ev);
-        case 13: return run_chunk_f64<13, 5>(p, a, stage_mask, ev);
-        case 14: return run_chunk_f64<14, 4>(p, a, stage_mask, ev);
+        case 10: return run_chunk_f64<10, 4, false>(p, a, stage_mask, ev);
+        case 11: return run_chunk_f64<11, 5, false>(p, a, stage_mask, ev);
+        case 12: return run_chunk_f64<12, 5, false>(p, a, stage_mask, ev);
+        case 13: return run_chunk_f64<13, 5, false>(p, a, stage_mask, ev);
+        case 14: return run_chunk_f64<14, 4, false>(p, a, stage_mask, ev);
         default: return HEXL_E_BADARG;
     }
 }

@@ -12,19 +12,23 @@ namespace hx {
 
 using hxf::Mod;
 
-template <int E, int OFF, int K, int S0>
+// LAZY (moduli <= hxf::LAZY_MAX_MODULUS): butterflies skip the range reduction except after every third
+// global stage and after the last one (bounds in f64_arith.hpp). LOGN is only needed to find the last stage.
+template <int E, int OFF, int K, int S0, int LOGN = 0, bool LAZY = false>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = w[base + j], Wp = wp[base + j];
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
-                hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m);
+                if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m);
+                else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m);
             }
         }
     }
@@ -32,7 +36,7 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 
 using hxf::InvScale;
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, bool LAZY = false>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -49,7 +53,8 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
                 const int a0 = OFF + (j << (u + 1)) + c;
                 const int a1 = a0 + (1 << u);
                 if (!fused) {
-                    hxf::gs_bfly(v[a0], v[a1], W, Wp, m);
+                    if (LAZY) hxf::gs_bfly_lazy(v[a0], v[a1], W, Wp, m);
+                    else      hxf::gs_bfly(v[a0], v[a1], W, Wp, m);
                 } else {                                   // last stage: scale both outputs by n^-1
                     const double s = v[a0] + v[a1], d = v[a0] - v[a1];
                     v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
@@ -70,7 +75,7 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
     __syncthreads();
 }
 
-template <int LOGN, int LOGE>
+template <int LOGN, int LOGE, bool LAZY = false>
 struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -82,7 +87,7 @@ struct WgNttF64 {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             const u32 Gp = (PASS == 0) ? 0u : (u32(tid) >> LO);
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1>(v, Gp, w, wp, m);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
                 redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
@@ -101,7 +106,7 @@ struct WgNttF64 {
                                                     const Mod m) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1>(v, Gbits, w, wp, m);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, LOGN, LAZY>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1>(v, tid, w, wp, m);
         }
     }
@@ -116,7 +121,7 @@ struct WgNttF64 {
                                                      const Mod m, const InvScale sc) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
-            inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1)>(v, Gbits, iw, iwp, m, sc);
+            inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY>(v, Gbits, iw, iwp, m, sc);
             inv_first<GRP + 1>(v, tid, iw, iwp, m, sc);
         }
     }
@@ -134,7 +139,7 @@ struct WgNttF64 {
                               [](int r, int t) { return G::template idxF<LO>(r, t); });
             }
             const u32 Gp = (PASS == G::P - 2) ? 0u : (u32(tid) >> LO);
-            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iw, iwp, m, sc);
+            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1>(v, lds, tid, iw, iwp, m, sc);
         }
     }

@@ -96,6 +96,62 @@ static void test_transforms(uint64_t n, uint64_t p) {
     }
 }
 
+// LAZY regime: replay the device schedules (ntt_core_f64.hpp) on the host, tracking the largest magnitude any
+// value reaches (must stay < 2^53) and checking results against the oracle.
+static double g_max_abs = 0;
+static inline void track(double x) { double a = x < 0 ? -x : x; if (a > g_max_abs) g_max_abs = a; }
+
+static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    int logn = 0; while ((1ull << logn) < n) ++logn;
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t *inv0 = blk.data(), *roots = blk.data() + 2 * n;
+    auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+    std::vector<uint64_t> x(n), ref;
+    orc_fill_splitmix(x.data(), n, p ^ (n + 7), p);
+    if (adversarial) for (uint64_t i = 0; i < n; ++i) x[i] = (i & 1) ? p / 2 : p / 2 + 1;   // extreme centred magnitudes
+    ref = x; orc_ks_ntt(ref.data(), n, p, roots);
+    std::vector<double> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
+    int s = 1;
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
+        const bool red = hxf::lazy_fwd_reduce_after(s, logn);
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]), wp = w / (double)p;
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (red) hxf::ct_bfly(v[j], v[j + t], w, wp, m); else hxf::ct_bfly_lazy(v[j], v[j + t], w, wp, m);
+                track(v[j]); track(v[j + t]);
+            }
+        }
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "lazy fwd n=%lu p=%lu i=%lu", n, p, i);
+    // inverse, last stage fused with the scaling exactly as inv_stages_f64 does
+    ref = x; orc_ks_intt(ref.data(), n, p, inv0);
+    for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
+    const double ninv = centre(orc_invmod(n, p)), ninv_p = ninv / (double)p;
+    const double nw = centre(orc_mulmod(orc_invmod(n, p), inv0[n - 2], p)), nw_p = nw / (double)p;
+    uint64_t acc = 0;
+    for (uint64_t mm = n >> 1, t = 1; mm >= 1; mm >>= 1, t <<= 1) {
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(inv0[acc + i]), wp = w / (double)p;
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (mm > 1) {
+                    hxf::gs_bfly_lazy(v[j], v[j + t], w, wp, m);
+                } else {
+                    const double sum = v[j] + v[j + t], dif = v[j] - v[j + t];
+                    track(sum); track(dif);
+                    v[j] = hxf::reduce(hxf::mul_shoup(sum, ninv, ninv_p, m), m);
+                    v[j + t] = hxf::reduce(hxf::mul_shoup(dif, nw, nw_p, m), m);
+                }
+                track(v[j]); track(v[j + t]);
+            }
+        }
+        acc += mm;
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "lazy inv n=%lu p=%lu i=%lu", n, p, i);
+}
+
 int main() {
     std::vector<uint64_t> primes;
     uint64_t tmp[8];
@@ -110,6 +166,19 @@ int main() {
     for (uint64_t p : primes) {
         test_transforms(1024, p);
         if (p > (1ull << 50)) test_transforms(16384, p);
+    }
+    // lazy schedules: only moduli <= LAZY_MAX_MODULUS; include the largest admissible prime = 1 mod 2^15
+    {
+        std::vector<uint64_t> lazy_primes(primes.begin(), primes.begin() + 8);
+        for (uint64_t v = ((uint64_t)hxf::LAZY_MAX_MODULUS / 32768) * 32768 + 1; v > (1ull << 51); v -= 32768)
+            if (orc_is_prime(v)) { lazy_primes.push_back(v); break; }
+        lazy_primes.push_back(primes[primes.size() - 3]);      // a 30-bit prime
+        for (uint64_t p : lazy_primes) {
+            CHECK((double)p <= hxf::LAZY_MAX_MODULUS, "prime %lu not lazy-admissible", p);
+            for (uint64_t n : {1024ull, 2048ull, 16384ull}) { test_transforms_lazy(n, p, false); test_transforms_lazy(n, p, true); }
+        }
+        std::printf("lazy schedules: max |x| seen = 2^%.3f (limit 2^53)\n", log2(g_max_abs));
+        CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded");
     }
     std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());
     return failures ? 1 : 0;

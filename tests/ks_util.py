@@ -5,9 +5,9 @@ import numpy as np
 
 
 class KsCase:
-    def __init__(self, orc, n, L, K, seed=1, bits=51, with_twiddles=False):
+    def __init__(self, orc, n, L, K, seed=1, bits=51, with_twiddles=False, moduli=None):
         self.n, self.L, self.K, self.rns = n, L, K, L + 1
-        self.moduli = np.array(orc.primes(K, bits, n), dtype=np.uint64)
+        self.moduli = np.array(orc.primes(K, bits, n) if moduli is None else moduli, dtype=np.uint64)
         q_sp = int(self.moduli[K - 1])
         self.modswitch = np.array([orc.orc().orc_invmod(q_sp % int(q), int(q)) if i < K - 1 else 1
                                    for i, q in enumerate(self.moduli)], dtype=np.uint64)
@@ -40,3 +40,13 @@ class KsCase:
         out = r.copy()
         orc.keyswitch(out, t, self.n, self.L, self.K, self.rns, self.moduli, self.keys, self.modswitch, self.twiddles)
         return out
+
+
+def primes_below(orc, count, limit, n):
+    """the `count` largest primes p < limit with p = 1 (mod 2n), descending"""
+    out, v = [], (limit - 2) // (2 * n) * (2 * n) + 1
+    while len(out) < count:
+        if v < limit and orc.orc().orc_is_prime(v):
+            out.append(v)
+        v -= 2 * n
+    return out

@@ -4,7 +4,7 @@ tests/test_keyswitch.cpp:148-191 (vectors 16384_6_7_7_2 / 8192_.., one worksize 
 import numpy as np
 import pytest
 
-from ks_util import KsCase
+from ks_util import KsCase, primes_below
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +30,31 @@ def test_vs_oracle(hx, ctx, dev, orc, n, L, K):
     got = run_gpu(hx, ctx, dev, case, ts, rs)
     for b in range(nb):
         assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"instance {b}"
+
+
+@pytest.mark.parametrize("which", ["f64_lazy_51bit", "f64_strict_just_below_2^52", "int_55bit", "int_forced_51bit",
+                                   "f64_strict_forced_51bit", "mixed_30_to_52bit"])
+def test_every_arithmetic_path(hx, ctx, dev, orc, monkeypatch, which):
+    """the three kernel families must agree with the oracle: FP64 lazy (all moduli <= 2^51(1+2^-7)), FP64 strict
+    (any modulus < 2^52) and the 64-bit integer kernels (moduli up to 2^60, also reachable with HEXL_KS_INT=1)"""
+    n, L, K = 16384, 3, 4
+    moduli = None
+    if which == "f64_strict_just_below_2^52":
+        moduli = primes_below(orc, K, 1 << 52, n)
+    elif which == "int_55bit":
+        moduli = orc.primes(K, 55, n)
+    elif which == "mixed_30_to_52bit":                      # like the SEAL bridge run: 52,30,30,40,... bit primes
+        moduli = [primes_below(orc, 1, 1 << 52, n)[0], orc.primes(1, 30, n)[0], orc.primes(1, 40, n)[0],
+                  orc.primes(2, 51, n)[1]]
+    if which == "int_forced_51bit":
+        monkeypatch.setenv("HEXL_KS_INT", "1")
+    if which == "f64_strict_forced_51bit":
+        monkeypatch.setenv("HEXL_KS_NOLAZY", "1")
+    case = KsCase(orc, n, L, K, seed=17, moduli=moduli)
+    ts, rs = zip(*[case.inputs(orc, b) for b in range(2)])
+    got = run_gpu(hx, ctx, dev, case, ts, rs)
+    for b in range(2):
+        assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"{which} instance {b}"
 
 
 def test_caller_twiddles_honoured(hx, ctx, dev, orc):
