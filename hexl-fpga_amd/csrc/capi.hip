@@ -378,21 +378,38 @@ extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* h_out, co
 extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, const uint64_t* const* h_t_targets,
                                    size_t batch) {
     if (!p || !h_results || !h_t_targets) return HEXL_E_BADARG;
+    if (!batch) return 0;
     hexl_ctx* c = p->ctx;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t tt = size_t(p->L) * p->n * 8, rs = 2 * tt;
+    const size_t n = p->n, L = p->L;
+    const size_t tt = L * n * 8, rs = 2 * tt;
     int rc = stage_reserve(c, batch * (tt + rs));
     if (rc) return rc;
     char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    for (size_t b = 0; b < batch; ++b) {                                 // copyKeySwitchBatch, fpga.cpp:542-555
-        memcpy(h + b * tt, h_t_targets[b], tt);
-        memcpy(h + batch * tt + b * rs, h_results[b], rs);
-    }
-    HX_CHECK(hipMemcpyAsync(d, h, batch * (tt + rs), hipMemcpyHostToDevice, c->stream));
+    for (size_t b = 0; b < batch; ++b) memcpy(h + b * tt, h_t_targets[b], tt);       // copyKeySwitchBatch, fpga.cpp:542-555
+    HX_CHECK(hipMemcpyAsync(d, h, batch * tt, hipMemcpyHostToDevice, c->stream));
+    // Like the reference, the device produces the keyswitch output only (the kernel accumulates into a zeroed
+    // buffer) and the HOST adds it into the caller's result, object by object in submission order
+    // (FPGAObject_KeySwitch::fill_out_data, fpga.cpp:441-475). This keeps the semantics when several objects of a
+    // batch alias the same result array, as benchmark/bench_keyswitch.cpp:113-131 does.
+    HX_CHECK(hipMemsetAsync(d + batch * tt, 0, batch * rs, c->stream));
     rc = hexl_keyswitch(p, (u64*)(d + batch * tt), (u64*)d, batch);
     if (rc) return rc;
     HX_CHECK(hipMemcpyAsync(h + batch * tt, d + batch * tt, batch * rs, hipMemcpyDeviceToHost, c->stream));
     HX_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < batch; ++b) memcpy(h_results[b], h + batch * tt + b * rs, rs);
+    for (size_t b = 0; b < batch; ++b) {
+        const u64* out = (const u64*)(h + batch * tt + b * rs);
+        u64* res = h_results[b];
+        for (size_t k = 0; k < 2; ++k)
+            for (size_t i = 0; i < L; ++i) {
+                const u64 q = p->moduli[i];
+                const u64* o = out + (k * L + i) * n;
+                u64* r = res + (k * L + i) * n;
+                for (size_t j = 0; j < n; ++j) {
+                    const u64 v = r[j] + o[j];
+                    r[j] = v >= q ? v - q : v;
+                }
+            }
+    }
     return 0;
 }

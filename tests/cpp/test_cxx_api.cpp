@@ -117,6 +117,21 @@ static void test_keyswitch(uint64_t n, uint64_t L, uint64_t K, size_t batch) {
     for (size_t b = 0; b < batch; ++b) CHECK(r[b] == ref[b], "keyswitch n=%lu L=%lu K=%lu obj %zu", n, L, K, b);
 }
 
+// several objects of one batch alias the same result array (benchmark/bench_keyswitch.cpp:113-131 submits the
+// same vectors n_iter times in one worksize window): outputs must accumulate in submission order
+static void test_keyswitch_aliased_results() {
+    KsSetup ks(8192, 3, 4, 77);
+    vec t, r, ref;
+    ks.make(t, r, 5);
+    ref = r;
+    for (int it = 0; it < 3; ++it) ks.expect(ref, t);
+    set_worksize_KeySwitch(3);
+    for (int it = 0; it < 3; ++it)
+        KeySwitch(r.data(), t.data(), ks.n, ks.L, ks.K, ks.L + 1, 2, ks.moduli.data(), ks.key_ptrs.data(), ks.msf.data());
+    KeySwitchCompleted();
+    CHECK(r == ref, "aliased result arrays inside one batch");
+}
+
 // mixed op types and parameter changes inside one worksize window (fences), like
 // tests/test_dyadic_multiply_keyswitch.cpp:295-313
 static void test_mixed_and_fences() {
@@ -155,6 +170,7 @@ int main() {
     test_keyswitch(16384, 6, 7, 3);                                               // the 16384_6_7_7_2 shape
     test_keyswitch(8192, 5, 7, 2);                                                // the 8192_5_7_6_2-like shape
     test_keyswitch(1024, 1, 2, 2);
+    test_keyswitch_aliased_results();
     test_mixed_and_fences();
     release_FPGA_resources();
     std::printf(failures ? "CXX API: %d FAILURE(S)\n" : "CXX API: ALL PASSED\n", failures);

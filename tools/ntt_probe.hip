@@ -125,6 +125,89 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_dual(double* x, const do
     for (int r = 0; r < G::E; ++r) pb[r * G::T + tid] = b[r];
 }
 
+// ---- half-size LDS exchange: the re-deal goes through LDS in two halves (index < N/2, then >= N/2), so a
+// workgroup needs 70 KiB instead of 140 KiB and TWO workgroups fit on a CU (512 threads x 32 coefficients each,
+// 128 VGPRs): one's stalls (loads, barriers, LDS) are covered by the other's FP64 work.
+template <int LOGN, int LOGE, bool LAZY>
+struct HalfX {
+    using G = Geom<LOGN, LOGE>;
+    static constexpr int E = G::E;
+    static constexpr int HALF_WORDS = G::LDS_WORDS / 2;
+    template <class FromIdx, class ToIdx>
+    __device__ static __forceinline__ void redeal(double (&v)[E], double* lds, int tid, FromIdx from, ToIdx to) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const int idx = from(r, tid);
+                if ((idx >> (LOGN - 1)) == half) lds[G::pad(idx & (G::N / 2 - 1))] = v[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const int idx = to(r, tid);
+                if ((idx >> (LOGN - 1)) == half) v[r] = lds[G::pad(idx & (G::N / 2 - 1))];
+            }
+            __syncthreads();
+        }
+    }
+    template <int PASS>
+    __device__ static __forceinline__ void pass(double (&v)[E], double* lds, int tid, const double* w, const double* wp, const Mod m) {
+        if constexpr (PASS < G::P - 1) {
+            constexpr int LO = LOGN - (PASS + 1) * LOGE;
+            const u32 Gp = (PASS == 0) ? 0u : (u32(tid) >> LO);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
+            if constexpr (PASS + 1 < G::P - 1) {
+                constexpr int LO2 = LO - LOGE;
+                redeal(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); }, [](int r, int t) { return G::template idxF<LO2>(r, t); });
+            } else {
+                redeal(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); }, [](int r, int t) { return G::idxB(r, t); });
+            }
+            pass<PASS + 1>(v, lds, tid, w, wp, m);
+        } else {
+            WgNttF64<LOGN, LOGE, LAZY>::template fwd_last<0>(v, tid, w, wp, m);
+        }
+    }
+};
+
+template <int LOGN, int LOGE, bool LAZY, int WPS, int STAGGER = 0>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), WPS) void k_halfx(double* x, const double* w, const double* wp, Mod m) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    double* px = x + size_t(blockIdx.x) * G::N;
+    double v[G::E];
+    // two co-resident workgroups that start together run their phases in lockstep and never overlap; a one-time
+    // stagger of the first wave of workgroups (every second one waits ~half a transform) breaks the symmetry
+    if (blockIdx.x < 512 && (blockIdx.x & 1)) {
+        for (int i = 0; i < STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = px[G::idxA(r, tid)];
+    HalfX<LOGN, LOGE, LAZY>::template pass<0>(v, ldsd, tid, w, wp, m);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) px[r * G::T + tid] = v[r];
+}
+
+template <int LOGN, int LOGE, bool LAZY, int WPS, int STAGGER = 0>
+float run_halfx(double* d, const double* w, const double* wp, int batch, const char* name) {
+    using G = Geom<LOGN, LOGE>;
+    Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
+    const int lb = (int)(HalfX<LOGN, LOGE, LAZY>::HALF_WORDS * 8 + 64);
+    auto kern = k_halfx<LOGN, LOGE, LAZY, WPS, STAGGER>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+    int nblk = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, kern, G::T, lb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(G::T), lb, 0, d, w, wp, m);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(batch), dim3(G::T), lb, 0, d, w, wp, m);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    printf("E=%2d HALFX %-28s blocks/CU=%d  %8.3f ms  %6.2f us/NTT/CU  %6.2f M NTT/s\n", 1 << LOGE, name, nblk, ms, ms * 1e3 / (batch / 256.0), batch / ms / 1e3);
+    return ms;
+}
+
 template <int LOGN, int LOGE>
 float run_dual(double* d, const double* w, const double* wp, int batch) {
     using G = Geom<LOGN, LOGE>;
@@ -191,6 +274,32 @@ int main() {
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     }
     run_dual<14, 4>(d, w, wp, batch);
+    {   // correctness of the half-exchange kernel vs the single one (E=32 outputs are in the E=32 B order: compare sorted sums)
+        std::vector<double> r1(size_t(4) * N), r2(size_t(4) * N);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
+        const size_t LB5 = Geom<14, 5>::LDS_BYTES;
+        { const int lb = (int)LB5; hipFuncSetAttribute((const void*)k_probe<14, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lb); }
+        hipLaunchKernelGGL((k_probe<14, 5, 0>), dim3(4), dim3(512), LB5, 0, d, w, wp, m);
+        hipMemcpy(r1.data(), d, r1.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        const int lbh = (int)(HalfX<14, 5, false>::HALF_WORDS * 8 + 64);
+        auto kh = k_halfx<14, 5, false, 4>;
+        hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, lbh);
+        hipLaunchKernelGGL(kh, dim3(4), dim3(512), lbh, 0, d, w, wp, m);
+        hipMemcpy(r2.data(), d, r2.size() * 8, hipMemcpyDeviceToHost);
+        size_t bad = 0; for (size_t i = 0; i < r1.size(); ++i) bad += r1[i] != r2[i];
+        printf("halfx vs single (E=32) mismatches: %zu\n", bad);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    }
+    run_halfx<14, 5, false, 4>(d, w, wp, batch, "strict, 128 VGPR cap");
+    run_halfx<14, 5, true, 4>(d, w, wp, batch, "lazy, 128 VGPR cap");
+    run_halfx<14, 5, true, 2>(d, w, wp, batch, "lazy, 256 VGPR (1 WG/CU)");
+    run_halfx<14, 5, false, 4, 1>(d, w, wp, batch, "strict, stagger 1");
+    run_halfx<14, 5, false, 4, 2>(d, w, wp, batch, "strict, stagger 2");
+    run_halfx<14, 5, false, 4, 3>(d, w, wp, batch, "strict, stagger 3");
+    run_halfx<14, 5, false, 4, 5>(d, w, wp, batch, "strict, stagger 5");
+    run_halfx<14, 5, true, 4, 3>(d, w, wp, batch, "lazy, stagger 3");
     run<14, 5, 0>(d, w, wp, batch, "full");
     run<14, 5, 9>(d, w, wp, batch, "no global load/store");
     run<14, 5, 15>(d, w, wp, batch, "ALU only");
