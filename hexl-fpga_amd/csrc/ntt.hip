@@ -59,7 +59,8 @@ u32 hx_loge_for(u32 logn) {
         const char* e = getenv("HEXL_NTT_LOGE");
         forced = e ? atoi(e) : 0;
     }
-    if (logn == 14 && forced == 4) return 4;
+    // N = 16384: 16 coefficients per thread x 1024 threads (4 waves/SIMD) measured ~10 % faster than 32 x 512
+    if (logn == 14) return forced == 5 ? 5 : 4;
     return logn <= 10 ? 4 : 5;
 }
 

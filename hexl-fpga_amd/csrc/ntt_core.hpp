@@ -40,6 +40,28 @@ __device__ __forceinline__ u64 lazy_mul(u64 x, u64 w, u64 wp, u64 q) { return w 
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
 
+// The same two operations written for the gfx950 VALU (identical results mod 2^64):
+//  * the subtraction W*x - Qh*q becomes an addition with nq = 2^64 - q, so both 64x64 low products share one
+//    v_mad_u64_u32 accumulator chain and the four cross terms only touch the high dword (32-bit mul + add3);
+//  * x - m is x + (2^64 - m): one v_lshl_add_u64 instead of a v_sub_co/v_subb_co pair with its VCC hazard nops.
+// ~27 instead of ~36 VALU instructions per butterfly.
+struct ModConst { u64 q, twoq, nq, n2q; };           // q, 2q, -q, -2q (mod 2^64)
+__device__ __forceinline__ ModConst mod_const(u64 q) { return ModConst{q, q << 1, 0 - q, 0 - (q << 1)}; }
+
+__device__ __forceinline__ u64 lazy_mul_n(u64 x, u64 w, u64 wp, u64 nq) {
+    const u64 qh = mulhi(x, wp);
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+    const u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    u64 acc = (u64)w0 * x0;
+    acc += (u64)h0 * n0;
+    const u32 hi = (u32)(acc >> 32) + w0 * x1 + w1 * x0 + h0 * n1 + h1 * n0;
+    return ((u64)hi << 32) | (u32)acc;
+}
+__device__ __forceinline__ u64 csub_n(u64 x, u64 m, u64 negm) {
+    const u64 d = x + negm;
+    return x >= m ? d : x;
+}
+
 // Twiddle loads do not depend on the loop a transform sits in (polynomial / decomposition index), so
 // LICM hoists ALL of them out of that loop and the register allocator spills hundreds of VGPRs
 // (measured: 0 -> 250 spills). Laundering the table pointer inside the loop body pins the loads.
@@ -83,6 +105,7 @@ struct Geom {
 template <int E, int OFF, int K, int S0>
 __device__ __forceinline__ void fwd_stages(u64 (&v)[E], u32 G, const u64* __restrict__ roots,
                                            const u64* __restrict__ precon, u64 q, u64 twoq) {
+    const ModConst mc = mod_const(q);
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
@@ -95,8 +118,8 @@ __device__ __forceinline__ void fwd_stages(u64 (&v)[E], u32 G, const u64* __rest
                 const int a0 = OFF + (j << (K - u)) + c;
                 const int a1 = a0 + (1 << (K - 1 - u));
                 const u64 X = v[a0], Y = v[a1];
-                const u64 tx = csub(X, twoq);              // fwd_ntt.cpp:322-323
-                const u64 Q = lazy_mul(Y, W, Wp, q);       // :336-354
+                const u64 tx = csub_n(X, twoq, mc.n2q);    // fwd_ntt.cpp:322-323
+                const u64 Q = lazy_mul_n(Y, W, Wp, mc.nq); // :336-354
                 v[a0] = tx + Q;                            // :359
                 v[a1] = tx + twoq - Q;                     // :360
             }
@@ -113,6 +136,7 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[E], u32 G, const u64* __rest
                                            const u64* __restrict__ iprecon, u64 q, u64 twoq,
                                            u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p) {
     constexpr u32 N = 1u << LOGN;
+    const ModConst mc = mod_const(q);
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const bool fused = LAST && (u == K - 1);
@@ -126,14 +150,14 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[E], u32 G, const u64* __rest
                 const int a0 = OFF + (j << (u + 1)) + c;
                 const int a1 = a0 + (1 << u);
                 const u64 X = v[a0], Y = v[a1];
-                const u64 tx = csub(X + Y, twoq);          // inv_ntt.cpp:300-304
+                const u64 tx = csub_n(X + Y, twoq, mc.n2q);  // inv_ntt.cpp:300-304
                 const u64 ty = X + twoq - Y;
                 if (!fused) {
                     v[a0] = tx;
-                    v[a1] = lazy_mul(ty, W, Wp, q);        // :305-306
+                    v[a1] = lazy_mul(ty, W, Wp, q);          // :305-306 (the fused-accumulator form compiles worse here)
                 } else {
-                    v[a0] = csub(lazy_mul(tx, inv_n, inv_n_p, q), q);      // :413-432
-                    v[a1] = csub(lazy_mul(ty, inv_n_w, inv_n_w_p, q), q);
+                    v[a0] = csub_n(lazy_mul_n(tx, inv_n, inv_n_p, mc.nq), q, mc.nq);      // :413-432
+                    v[a1] = csub_n(lazy_mul_n(ty, inv_n_w, inv_n_w_p, mc.nq), q, mc.nq);
                 }
             }
             HX_SCHED_FENCE(j);
@@ -198,9 +222,9 @@ struct WgNtt {
     }
     // fwd_ntt.cpp:369-384
     __device__ static __forceinline__ void final_reduce(u64 (&v)[E], u64 q) {
-        const u64 twoq = q << 1;
+        const ModConst mc = mod_const(q);
 #pragma unroll
-        for (int r = 0; r < E; ++r) v[r] = csub(csub(v[r], twoq), q);
+        for (int r = 0; r < E; ++r) v[r] = csub_n(csub_n(v[r], mc.twoq, mc.n2q), q, mc.nq);
     }
 
     // ---- inverse: v in B layout on entry, A layout on exit; values in [0,q) -----------------
