@@ -61,14 +61,17 @@ __device__ __forceinline__ u64 mulmod_barrett(u64 x, u64 y, u64 q, u32 len, u64 
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
+// VEC = 2: two adjacent coefficients per thread (n even; 16-byte accesses). VEC = 1: any n (the reference only
+// requires n > 0, host/src/dyadic_multiply.cpp:15-26, and its tests go down to n = 256).
+template <int VEC>
 __global__ __launch_bounds__(256) void k_dyadic(u64* __restrict__ out, const u64* __restrict__ a,
                                                 const u64* __restrict__ b,
                                                 const DyMeta* __restrict__ meta, u32 n, u32 n_moduli,
-                                                u32 pairs_per_row /* n/2 */, u64 total_pairs) {
+                                                u32 pairs_per_row /* n/VEC */, u64 total_pairs) {
     const u64 gid = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= total_pairs) return;
-    const u64 row = gid / pairs_per_row;              // (item, limb); uniform per block since n/2 % 256 == 0
-    const u32 j = u32(gid - row * pairs_per_row) * 2;
+    const u64 row = gid / pairs_per_row;              // (item, limb)
+    const u32 j = u32(gid - row * pairs_per_row) * VEC;
     const u64 item = row / n_moduli;
     const u32 m = u32(row - item * n_moduli);
     const DyMeta md = meta[row];
@@ -77,14 +80,20 @@ __global__ __launch_bounds__(256) void k_dyadic(u64* __restrict__ out, const u64
 
     const u64 in_base = (item * 2 * n_moduli + m) * u64(n) + j;        // x0 / y0
     const u64 in_p1 = in_base + u64(n_moduli) * n;                     // x1 / y1
-    u64x2 x0 = *reinterpret_cast<const u64x2*>(a + in_base);
-    u64x2 x1 = *reinterpret_cast<const u64x2*>(a + in_p1);
-    u64x2 y0 = *reinterpret_cast<const u64x2*>(b + in_base);
-    u64x2 y1 = *reinterpret_cast<const u64x2*>(b + in_p1);
+    u64x2 x0, x1, y0, y1;
+    if constexpr (VEC == 2) {
+        x0 = *reinterpret_cast<const u64x2*>(a + in_base);
+        x1 = *reinterpret_cast<const u64x2*>(a + in_p1);
+        y0 = *reinterpret_cast<const u64x2*>(b + in_base);
+        y1 = *reinterpret_cast<const u64x2*>(b + in_p1);
+    } else {
+        x0[0] = a[in_base]; x1[0] = a[in_p1]; y0[0] = b[in_base]; y1[0] = b[in_p1];
+        x0[1] = x1[1] = y0[1] = y1[1] = 0;
+    }
 
     u64x2 r0, r1, r2;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < VEC; ++e) {
         u64 a0 = x0[e], a1 = x1[e], b0 = y0[e], b1 = y1[e];
         // in-range data (the benchmark / SEAL case) skips the operand reduction wave-uniformly
         if (__any((a0 >= q) | (a1 >= q) | (b0 >= q) | (b1 >= q))) {
@@ -101,23 +110,35 @@ __global__ __launch_bounds__(256) void k_dyadic(u64* __restrict__ out, const u64
     }
     const u64 out_base = (item * 3 * n_moduli + m) * u64(n) + j;
     const u64 stride = u64(n_moduli) * n;
-    *reinterpret_cast<u64x2*>(out + out_base) = r0;
-    *reinterpret_cast<u64x2*>(out + out_base + stride) = r1;
-    *reinterpret_cast<u64x2*>(out + out_base + 2 * stride) = r2;
+    if constexpr (VEC == 2) {
+        *reinterpret_cast<u64x2*>(out + out_base) = r0;
+        *reinterpret_cast<u64x2*>(out + out_base + stride) = r1;
+        *reinterpret_cast<u64x2*>(out + out_base + 2 * stride) = r2;
+    } else {
+        out[out_base] = r0[0]; out[out_base + stride] = r1[0]; out[out_base + 2 * stride] = r2[0];
+    }
 }
 
 int hx_launch_dyadic(hexl_ctx* ctx, u64* d_out, const u64* d_a, const u64* d_b, size_t batch, u64 n,
                      const u64* d_moduli, u64 n_moduli) {
     if (!batch || !n_moduli) return 0;
-    if (n < 512 || (n & (n - 1)) || n > (1u << 20)) return HEXL_E_BADARG;   // n/2 must be a multiple of 256
+    if (n == 0 || n > (1u << 24)) return HEXL_E_BADARG;
     const size_t rows = batch * n_moduli;
     int rc = hx_reserve_device(ctx, &ctx->d_meta, &ctx->d_meta_bytes, rows * sizeof(DyMeta));
     if (rc) return rc;
     DyMeta* meta = (DyMeta*)ctx->d_meta;
     hipLaunchKernelGGL(k_dyadic_meta, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, meta,
                        d_moduli, (u32)rows);
-    const u64 total_pairs = u64(rows) * (n / 2);
-    hipLaunchKernelGGL(k_dyadic, dim3((unsigned)((total_pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_out,
-                       d_a, d_b, meta, (u32)n, (u32)n_moduli, (u32)(n / 2), total_pairs);
+    // 16-byte accesses need every row to start 16-byte aligned: n even and 16-byte aligned base pointers
+    const bool vec2 = (n % 2 == 0) && (((uintptr_t)d_out | (uintptr_t)d_a | (uintptr_t)d_b) % 16 == 0);
+    if (vec2) {
+        const u64 total = u64(rows) * (n / 2);
+        hipLaunchKernelGGL(k_dyadic<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_a,
+                           d_b, meta, (u32)n, (u32)n_moduli, (u32)(n / 2), total);
+    } else {
+        const u64 total = u64(rows) * n;
+        hipLaunchKernelGGL(k_dyadic<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_a,
+                           d_b, meta, (u32)n, (u32)n_moduli, (u32)n, total);
+    }
     return (int)hipGetLastError();
 }

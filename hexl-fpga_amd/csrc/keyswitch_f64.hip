@@ -45,15 +45,22 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), md.m);
+    // step 2 for slot == d needs no transform: NTT_{q_d}(INTT_{q_d}(t_d) mod q_d) = t_d (the reference recomputes
+    // it; same value for in-range data). The registers already hold t_d in B order.
+    {
+        const u32 b = item / a.L;
+        double* ud = a.u + ((size_t(b) * (a.L + 1) + d) * a.L + d) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) ud[r * G::T + tid] = v[r];
+    }
     WgNttF64<LOGN, LOGE, LAZY>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
     double* dst = a.c + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = hxf::lift(v[r], md.m);
 }
 
-// step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i), one transform per workgroup, kept in the forward
-// transform's register order ("B order", fully coalesced). slot == d needs no transform: c_d = INTT(t_d) and
-// the moduli agree, so u = t_target[d] (the reference recomputes it; the value is identical for in-range data).
+// step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i) for slot != d (slot == d is written by k_ksf_intt), one
+// transform per workgroup, kept in the forward transform's register order ("B order", fully coalesced).
 template <int LOGN, int LOGE, bool LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
@@ -61,20 +68,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
-    const u32 item = xcd_item_f(blockIdx.x, gridDim.x);           // (slot*L + d)*nb + b : one XCD works on one (slot, d)
-    const u32 sd = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - sd * a.nb;
-    const u32 slot = sd / L, d = sd - slot * L;
+    const u32 item = xcd_item_f(blockIdx.x, gridDim.x);           // pair*nb + b : one XCD works on one (slot, d) pair
+    const u32 pr = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - pr * a.nb;
+    // pairs with slot != d: L-1 per ordinary slot, then L for the special-prime slot
+    u32 slot, d;
+    if (pr < L * (L - 1)) { slot = pr / (L - 1); d = pr - slot * (L - 1); d += (d >= slot); }
+    else                  { slot = L; d = pr - L * (L - 1); }
     const u32 i = slot < L ? slot : a.K - 1;
     const KsModF64 md = a.mods[i];
     const Mod m = md.m;
     double* dst = a.u + ((size_t(b) * (L + 1) + slot) * L + d) * G::N;
     double v[G::E];
-    if (slot == d) {
-        const u64* src = a.t_target + (size_t(b) * L + d) * G::N;
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), m);
-        return;
-    }
     const double* cd = a.c + (size_t(b) * L + d) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(cd[G::idxA(r, tid)], m);          // c_d mod q_i (intt1_redu.hpp:36-42)
@@ -205,7 +209,7 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
         hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2) {
-        hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * (L + 1) * L), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * L * L), dim3(G::T), G::LDS_BYTES, st, a);
         const u32 threads = (L + 1) * (G::N / 2);
         const u32 by = nb < 8 ? nb : 8;                            // 8 batch lanes keep >= 2048 workgroups in flight
         if (L <= 8) hipLaunchKernelGGL((k_ksf_mac<8>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);

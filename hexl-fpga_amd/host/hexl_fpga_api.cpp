@@ -226,7 +226,7 @@ void set_worksize_DyadicMultiply(uint64_t ws) {
 void DyadicMultiply(uint64_t* results, const uint64_t* operand1, const uint64_t* operand2, uint64_t n,
                     const uint64_t* moduli, uint64_t n_moduli) {
     REQUIRE(results && operand1 && operand2 && moduli, "DyadicMultiply: null pointer");
-    REQUIRE(pow2_in(n, 1024, 32768), "DyadicMultiply: requires n = 1024 ... 32768");       // dyadic_multiply.cpp:19-22
+    REQUIRE(n > 0, "DyadicMultiply: n must be a positive integer");                        // dyadic_multiply.cpp:19
     REQUIRE(n_moduli > 0, "DyadicMultiply: requires n_moduli > 0");
     Engine& e = eng();
     std::lock_guard<std::mutex> lk(e.mu_dy);

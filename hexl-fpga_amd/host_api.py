@@ -55,8 +55,8 @@ class HexlFpga:
         self._ws["dyadic"] = int(ws)
 
     def DyadicMultiply(self, results, operand1, operand2, n: int, moduli, n_moduli: int):
-        if n not in (1024, 2048, 4096, 8192, 16384, 32768):
-            raise ValueError("requires n = 1024/2048/4096/8192/16384/32768")
+        if n <= 0 or n_moduli <= 0:                       # host/src/dyadic_multiply.cpp:19-21
+            raise ValueError("n and n_moduli must be positive integers")
         _u64(results, "results"), _u64(operand1, "operand1"), _u64(operand2, "operand2"), _u64(moduli, "moduli")
         q = self._q["dyadic"]
         if q and (q[0][3], q[0][5]) != (n, n_moduli):

@@ -25,7 +25,7 @@ def gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm):
     return hx.to_u64(out)
 
 
-@pytest.mark.parametrize("n,nm,num", [(512, 1, 2), (1024, 2, 16), (4096, 7, 3), (16384, 14, 2), (32768, 4, 2)])
+@pytest.mark.parametrize("n,nm,num", [(256, 1, 16), (255, 2, 3), (512, 1, 2), (1024, 2, 16), (4096, 7, 3), (16384, 14, 2), (32768, 4, 2)])
 def test_reference_toy_moduli(hx, ctx, dev, orc, n, nm, num):
     mod, a, b = ref_style_io(num, nm, n)
     got = gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm).reshape(num, 3, nm, n)
