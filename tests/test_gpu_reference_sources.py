@@ -29,3 +29,51 @@ def test_reference_benchmark_binary_runs(exe):
     out = subprocess.run([str(path), "--benchmark_min_time=0.05"], capture_output=True, text=True, timeout=1200)
     print(out.stdout[-1500:], out.stderr[-500:])
     assert out.returncode == 0 and "ms" in out.stdout
+
+
+def _vectors(tmp, n, shapes, count=2):
+    import sys
+    sys.path.insert(0, str(BUILD.parent))
+    import make_ks_vectors
+    for (L, K, rns) in shapes:
+        make_ks_vectors.main(str(tmp), n, L, K, rns, count)
+
+
+def test_reference_keyswitch_gtest(tmp_path):
+    """tests/test_keyswitch.cpp unmodified: JSON loader -> KeySwitch(worksize batch, caller twiddles) -> ASSERT_EQ"""
+    exe = BUILD / "test_keyswitch"
+    if not exe.exists():
+        pytest.skip("reference keyswitch test was not built on this box")
+    import os
+    _vectors(tmp_path, 4096, [(6, 7, 7), (5, 7, 6)])
+    env = dict(os.environ, KEYSWITCH_DATA_DIR=str(tmp_path), N="4096")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=1200, env=env)
+    print(out.stdout[-1500:], out.stderr[-500:])
+    assert out.returncode == 0 and "[  PASSED  ] 2 test(s)" in out.stdout
+
+
+def test_reference_dyadic_keyswitch_gtest(tmp_path):
+    """tests/test_dyadic_multiply_keyswitch.cpp unmodified (N = 16384 vectors, both primitives interleaved)"""
+    exe = BUILD / "test_dyadic_multiply_keyswitch"
+    if not exe.exists():
+        pytest.skip("reference combined test was not built on this box")
+    import os
+    _vectors(tmp_path, 16384, [(6, 7, 7)], count=2)
+    env = dict(os.environ, KEYSWITCH_DATA_DIR=str(tmp_path))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=1800, env=env)
+    print(out.stdout[-1500:], out.stderr[-500:])
+    assert out.returncode == 0 and "[  PASSED  ]" in out.stdout
+
+
+def test_reference_keyswitch_benchmark(tmp_path):
+    """benchmark/bench_keyswitch.cpp unmodified: ITER x the 16384_6_7_7_2 vectors in ONE worksize window, the same
+    result arrays submitted repeatedly (accumulation order matters, see hexl_keyswitch_host)"""
+    exe = BUILD / "bench_keyswitch"
+    if not exe.exists():
+        pytest.skip("reference keyswitch benchmark was not built on this box")
+    import os
+    _vectors(tmp_path, 16384, [(6, 7, 7)], count=2)
+    env = dict(os.environ, KEYSWITCH_DATA_DIR=str(tmp_path), ITER="4")
+    out = subprocess.run([str(exe), "--benchmark_min_time=0.05"], capture_output=True, text=True, timeout=1800, env=env)
+    print(out.stdout[-1500:], out.stderr[-500:])
+    assert out.returncode == 0 and "16384_6_7_7_2" in out.stdout
