@@ -159,8 +159,17 @@ def main():
         alg = ks_alg_bytes(N, L)
         ach = alg * a.batch * a.steps / (dev_ms * 1e-3) / 1e9          # this rank, device-timed
         stage = plan.time_stages(d_r, d_t, min(a.batch, 256), 3)
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE
+        # summed over the pipeline's kernels, separate --pmc runs); scaled from the profiled batch to this batch
+        traffic = None
+        tj = ROOT / "profiles" / "traffic_latest.json"
+        if tj.exists():
+            t = json.loads(tj.read_text())
+            if t.get("L") == L:
+                traffic = t["keyswitch_traffic_bytes_per_unit"] * a.batch
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "alg_bytes_per_launch": alg * a.batch,
                            "kernel": "keyswitch pipeline (ks_intt + ks_modup + ks_moddown)",
                            "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps}
         extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "ks_intt": stage[1],

@@ -48,6 +48,7 @@ extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_meta) (void)hipFree(c->d_meta);
+    if (c->d_ntt_tab) (void)hipFree(c->d_ntt_tab);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -32,6 +32,7 @@ struct hexl_ctx {
     void* d_stage = nullptr;  size_t d_stage_bytes = 0;
     void* h_stage = nullptr;  size_t h_stage_bytes = 0;
     void* d_meta = nullptr;   size_t d_meta_bytes = 0;     // dyadic per-(item,modulus) constants
+    void* d_ntt_tab = nullptr; size_t d_ntt_tab_bytes = 0;  // standalone NTT fast path: derived double tables + flag
     char name[256] = {0};
 };
 

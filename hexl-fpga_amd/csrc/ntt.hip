@@ -6,8 +6,126 @@
 
 #include "hexl_internal.hpp"
 #include "ntt_core.hpp"
+#include "ntt_core_f64.hpp"
 
 using namespace hx;
+
+// ---------------------------------------------------------------------------------------------
+// Exact-arithmetic fast path. The Harvey kernels above must be replayed op for op only where that is observable:
+// out-of-range data, improper tables (benchmarks pass random ones), moduli >= 2^52. When q < 2^52, the tables
+// satisfy precon[i] == floor(roots[i]*2^64/q) with roots[i] < q, and the polynomial is inside the algorithm's
+// input range (< 4q forward, < 2q inverse), the reference's result is by construction the canonical transform
+// of (x mod q) -- which the FP64 butterflies of ntt_core_f64.hpp compute exactly with ~1/3 of the instructions.
+// k_ntt_prepare verifies the tables on the device (no division: 0 <= roots*2^64 - precon*q < q) and derives the
+// centred double tables; the transform kernels then choose per polynomial, falling back to the integer
+// butterflies whenever a precondition fails, so every input still gets the reference's exact answer.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q, u32 n,
+                              double* __restrict__ w, double* __restrict__ wp, u32* __restrict__ violations) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0) { w[0] = 0.0; wp[0] = 0.0; return; }          // index 0 is never read by either transform
+    const u64 r = roots[i], p = precon[i];
+    // 128-bit  D = r*2^64 - p*q  must satisfy 0 <= D < q
+    const u64 lo = p * q, hi = mulhi(p, q);
+    const u64 d_lo = 0 - lo, d_hi = r - hi - (lo != 0);
+    const bool ok = (r < q) && (hi + (lo != 0) <= r) && (d_hi == 0) && (d_lo < q);
+    if (!ok) atomicAdd(violations, 1u);
+    const double pd = (double)q;
+    const u64 rr = r < q ? r : 0;
+    const double c = rr > q / 2 ? (double)rr - pd : (double)rr;
+    w[i] = c;
+    wp[i] = c / pd;
+}
+
+template <int LOGN, int LOGE, bool LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restrict__ x, const u64* __restrict__ roots,
+                                                                  const u64* __restrict__ precon, u64 q,
+                                                                  const double* __restrict__ w,
+                                                                  const double* __restrict__ wp,
+                                                                  const u32* __restrict__ violations, u32 batch) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const u32 p = blockIdx.x;
+    if (p >= batch) return;
+    u64* px = x + size_t(p) * G::N;
+    u64 v[G::E];
+    const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
+    bool out_of_range = false;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) { v[r] = px[G::idxA(r, tid)]; out_of_range |= v[r] >= limit; }
+    const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);
+    if (!slow) {
+        const Mod m{(double)q, 1.0 / (double)q};
+        double f[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) f[r] = hxf::reduce(hxf::to_f64(v[r]), m);
+        WgNttF64<LOGN, LOGE, LAZY>::forward(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::from_f64(hxf::lift(f[r], m));
+    } else {
+        WgNtt<LOGN, LOGE>::forward_lazy(v, lds, tid, roots, precon, q);
+        WgNtt<LOGN, LOGE>::final_reduce(v, q);
+    }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = v[r];
+}
+
+template <int LOGN, int LOGE, bool LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restrict__ x, const u64* __restrict__ iroots,
+                                                                  const u64* __restrict__ iprecon, u64 q, u64 inv_n,
+                                                                  u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p,
+                                                                  const double* __restrict__ w,
+                                                                  const double* __restrict__ wp, hxf::InvScale sc,
+                                                                  const u32* __restrict__ violations, u32 batch) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const u32 p = blockIdx.x;
+    if (p >= batch) return;
+    u64* px = x + size_t(p) * G::N;
+    u64 v[G::E];
+    const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
+    bool out_of_range = false;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) { v[r] = px[G::idxB(r, tid)]; out_of_range |= v[r] >= limit; }
+    const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);
+    if (!slow) {
+        const Mod m{(double)q, 1.0 / (double)q};
+        double f[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) f[r] = hxf::reduce(hxf::to_f64(v[r]), m);
+        WgNttF64<LOGN, LOGE, LAZY>::inverse(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::from_f64(hxf::lift(f[r], m));
+    } else {
+        WgNtt<LOGN, LOGE>::inverse(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+    }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
+}
+
+static bool fast_path_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("HEXL_NTT_INT"); v = (e && atoi(e) == 1) ? 0 : 1; }
+    return v == 1;
+}
+
+// device scratch for the derived tables: [w | w/p] (n doubles each) + the violation counter
+static int prepare_tables(hexl_ctx* ctx, const u64* roots, const u64* precon, u64 q, u64 n, double** w, double** wp,
+                          u32** viol) {
+    const size_t bytes = 2 * n * sizeof(double) + 256;
+    int rc = hx_reserve_device(ctx, &ctx->d_ntt_tab, &ctx->d_ntt_tab_bytes, bytes);
+    if (rc) return rc;
+    *w = (double*)ctx->d_ntt_tab;
+    *wp = *w + n;
+    *viol = (u32*)(*wp + n);
+    HX_CHECK(hipMemsetAsync(*viol, 0, sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(k_ntt_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, roots, precon, q,
+                       (u32)n, *w, *wp, *viol);
+    return (int)hipGetLastError();
+}
 
 template <int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd(u64* __restrict__ x,
@@ -99,6 +217,61 @@ static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
     return (int)hipGetLastError();
 }
 
+template <int LOGN, int LOGE, bool LAZY>
+static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q,
+                        const double* w, const double* wp, const u32* viol) {
+    using G = Geom<LOGN, LOGE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_x<LOGN, LOGE, LAZY>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_BYTES, ctx->stream, x,
+                       roots, precon, q, w, wp, viol, (u32)batch);
+    return (int)hipGetLastError();
+}
+
+template <int LOGN, int LOGE, bool LAZY>
+static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const u64* ip, u64 q, u64 a, u64 ap, u64 b,
+                        u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* viol) {
+    using G = Geom<LOGN, LOGE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_x<LOGN, LOGE, LAZY>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_BYTES, ctx->stream, x,
+                       ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
+    return (int)hipGetLastError();
+}
+
+template <bool LAZY>
+static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, const double* w,
+                          const double* wp, const u32* v) {
+    switch (logn) {
+        case 10: return launch_fwd_x<10, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 11: return launch_fwd_x<11, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 12: return launch_fwd_x<12, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 13: return launch_fwd_x<13, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 14: return launch_fwd_x<14, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        default: return HEXL_E_BADARG;
+    }
+}
+template <bool LAZY>
+static int dispatch_inv_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, u64 a, u64 ap,
+                          u64 b, u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* v) {
+    switch (logn) {
+        case 10: return launch_inv_x<10, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 11: return launch_inv_x<11, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 12: return launch_inv_x<12, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 13: return launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 14: return launch_inv_x<14, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        default: return HEXL_E_BADARG;
+    }
+}
+
 static int ilog2_exact(u64 n) {
     for (int l = 0; l < 63; ++l)
         if ((1ULL << l) == n) return l;
@@ -108,6 +281,13 @@ static int ilog2_exact(u64 n) {
 int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q, u64 n) {
     if (!batch) return 0;
     const int logn = ilog2_exact(n);
+    if (fast_path_enabled() && q >= (1ull << 16) && q < (1ull << 52)) {
+        double *w, *wp; u32* viol;
+        int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol);
+        if (rc) return rc;
+        return (double)q <= hxf::LAZY_MAX_MODULUS ? dispatch_fwd_x<true>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
+                                                  : dispatch_fwd_x<false>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+    }
     switch (logn) {
         case 10: return launch_fwd<10, 4>(ctx, x, batch, roots, precon, q);
         case 11: return launch_fwd<11, 5>(ctx, x, batch, roots, precon, q);
@@ -124,6 +304,17 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
                       u64 b, u64 bp, u64 n) {
     if (!batch) return 0;
     const int logn = ilog2_exact(n);
+    if (fast_path_enabled() && q >= (1ull << 16) && q < (1ull << 52) && a < q && b < q) {
+        double *w, *wp; u32* viol;
+        int rc = prepare_tables(ctx, ir, ip, q, n, &w, &wp, &viol);
+        if (rc) return rc;
+        const double pd = (double)q;
+        auto centre = [&](u64 v) { return v > q / 2 ? (double)v - pd : (double)v; };
+        hxf::InvScale sc;
+        sc.n = centre(a); sc.n_p = sc.n / pd; sc.nw = centre(b); sc.nw_p = sc.nw / pd;
+        return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<true>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol)
+                                           : dispatch_inv_x<false>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol);
+    }
     switch (logn) {
         case 10: return launch_inv<10, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
         case 11: return launch_inv<11, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);

@@ -190,7 +190,8 @@ struct WgNtt {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // pass 0 has no index bits above its field: constant twiddle addresses -> scalar loads
-            const u32 Gp = (PASS == 0) ? 0u : (u32(tid) >> LO);
+            // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
+            const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             fwd_stages<E, 0, LOGE, PASS * LOGE + 1>(v, Gp, roots, precon, q, twoq);
             // hand over to the next pass's ownership
             if constexpr (PASS + 1 < G::P - 1) {
@@ -254,7 +255,7 @@ struct WgNtt {
                 redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
                           [](int r, int t) { return G::template idxF<LO>(r, t); });
             }
-            const u32 Gp = (PASS == G::P - 2) ? 0u : (u32(tid) >> LO);
+            const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iroots, iprecon, q, twoq, a, ap, b, bp);
             inv_pass<PASS + 1>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
         }

@@ -86,7 +86,8 @@ struct WgNttF64 {
                                                     const double* wp, const Mod m) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
-            const u32 Gp = (PASS == 0) ? 0u : (u32(tid) >> LO);
+            // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
+            const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
@@ -114,6 +115,27 @@ struct WgNttF64 {
                                                    const double* wp, const Mod m) {
         fwd_pass<0>(v, lds, tid, w, wp, m);
     }
+    // every pass except the last (partial) one, ending with the re-deal into B layout; fwd_last<0> finishes.
+    // Lets a persistent kernel slot the next polynomial's loads between the two.
+    template <int PASS>
+    __device__ static __forceinline__ void fwd_pass_until_last(double (&v)[E], double* lds, int tid, const double* w,
+                                                               const double* wp, const Mod m) {
+        if constexpr (PASS < G::P - 1) {
+            constexpr int LO = LOGN - (PASS + 1) * LOGE;
+            // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
+            const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
+            if constexpr (PASS + 1 < G::P - 1) {
+                constexpr int LO2 = LO - LOGE;
+                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                              [](int r, int t) { return G::template idxF<LO2>(r, t); });
+            } else {
+                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                              [](int r, int t) { return G::idxB(r, t); });
+            }
+            fwd_pass_until_last<PASS + 1>(v, lds, tid, w, wp, m);
+        }
+    }
 
     // inverse: B layout in, A layout out, centred, scaled by n^-1
     template <int GRP>
@@ -138,7 +160,7 @@ struct WgNttF64 {
                 redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
                               [](int r, int t) { return G::template idxF<LO>(r, t); });
             }
-            const u32 Gp = (PASS == G::P - 2) ? 0u : (u32(tid) >> LO);
+            const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1>(v, lds, tid, iw, iwp, m, sc);
         }

@@ -208,6 +208,61 @@ float run_halfx(double* d, const double* w, const double* wp, int batch, const c
     return ms;
 }
 
+// ---- persistent workgroups with register prefetch: one workgroup per CU walks a contiguous range of
+// polynomials; the next polynomial's coefficients are requested before the last (short) register pass of the
+// current one, so the HBM latency and the workgroup relaunch gap disappear from the critical path.
+template <int LOGN, int LOGE, bool LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_persist(double* x, const double* w, const double* wp, Mod m, int total) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per, last = min(total, first + per);
+    if (first >= last) return;
+    double v[G::E], nxt[G::E];
+    {
+        const double* px = x + size_t(first) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = px[G::idxA(r, tid)];
+    }
+    for (int item = first; item < last; ++item) {
+        const double* tw = opaque(w);
+        const double* twp = opaque(wp);
+        // all passes but the last
+        W::template fwd_pass_until_last<0>(v, ldsd, tid, tw, twp, m);
+        if (item + 1 < last) {
+            const double* pn = x + size_t(item + 1) * G::N;
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) nxt[r] = pn[G::idxA(r, tid)];
+        }
+        W::template fwd_last<0>(v, tid, tw, twp, m);
+        double* px = x + size_t(item) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) px[r * G::T + tid] = v[r];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = nxt[r];
+    }
+}
+
+template <int LOGN, int LOGE, bool LAZY>
+float run_persist(double* d, const double* w, const double* wp, int batch, int grid) {
+    using G = Geom<LOGN, LOGE>;
+    Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
+    const int lb = (int)G::LDS_BYTES;
+    auto kern = k_persist<LOGN, LOGE, LAZY>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::T), lb, 0, d, w, wp, m, batch);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(G::T), lb, 0, d, w, wp, m, batch);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    printf("E=%2d PERSIST lazy=%d grid=%d                               %8.3f ms  %6.2f us/NTT/CU  %6.2f M NTT/s\n", 1 << LOGE, (int)LAZY, grid, ms, ms * 1e3 / (batch / 256.0), batch / ms / 1e3);
+    return ms;
+}
+
 template <int LOGN, int LOGE>
 float run_dual(double* d, const double* w, const double* wp, int batch) {
     using G = Geom<LOGN, LOGE>;
@@ -274,6 +329,27 @@ int main() {
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     }
     run_dual<14, 4>(d, w, wp, batch);
+    {   // lazy single-shot reference for the persistent variants
+        using G4 = Geom<14, 4>;
+        Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
+        std::vector<double> r1(size_t(8) * N), r2(size_t(8) * N);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        const size_t LB = G4::LDS_BYTES;
+        hipLaunchKernelGGL((k_probe<14, 4, 0>), dim3(8), dim3(1024), LB, 0, d, w, wp, m);
+        hipMemcpy(r1.data(), d, r1.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        auto kp = k_persist<14, 4, false>;
+        { const int lb = (int)LB; hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, lb); }
+        hipLaunchKernelGGL(kp, dim3(3), dim3(1024), LB, 0, d, w, wp, m, 8);
+        hipMemcpy(r2.data(), d, r2.size() * 8, hipMemcpyDeviceToHost);
+        size_t bad = 0; for (size_t i = 0; i < r1.size(); ++i) bad += r1[i] != r2[i];
+        printf("persist vs single mismatches: %zu\n", bad);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    }
+    run_persist<14, 4, false>(d, w, wp, batch, 256);
+    run_persist<14, 4, true>(d, w, wp, batch, 256);
+    run_persist<14, 4, true>(d, w, wp, batch, 512);
+    run_halfx<14, 4, true, 1>(d, w, wp, batch, "E=16 lazy half-exchange, 1 WG");
     {   // correctness of the half-exchange kernel vs the single one (E=32 outputs are in the E=32 B order: compare sorted sums)
         std::vector<double> r1(size_t(4) * N), r2(size_t(4) * N);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
