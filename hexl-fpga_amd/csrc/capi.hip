@@ -50,6 +50,13 @@ extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->d_ntt_tab) (void)hipFree(c->d_ntt_tab);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->s_up) (void)hipStreamDestroy(c->s_up);
+    if (c->s_down) (void)hipStreamDestroy(c->s_down);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+        if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]);
+        if (c->ev_down[i]) (void)hipEventDestroy(c->ev_down[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -301,12 +308,101 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 }
 
 // ------------------------------------------------------------------------------- host-pointer variants
-// The reference stages every batch through device-visible memory (FPGAObject_*::fill_in_data /
-// fill_out_data, host/src/fpga.cpp:329-518); same here with one pinned bounce buffer per context.
-static int stage_reserve(hexl_ctx* c, size_t bytes) {
-    int rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, bytes);
+// The reference stages every batch through device-visible memory (FPGAObject_*::fill_in_data / fill_out_data,
+// host/src/fpga.cpp:329-518) with one batch in flight while the previous one is read back (:1517-1545). Here a
+// batch is cut into sub-batches that flow through a 3-stage pipeline with double-buffered pinned and device
+// slabs: CPU pack (parallel memcpy) -> H2D on its own stream -> kernels on the context stream -> D2H on a third
+// stream -> CPU unpack, so PCIe traffic in both directions, the kernels and the host copies overlap.
+#include <atomic>
+#include <functional>
+#include <thread>
+
+static unsigned host_threads() {
+    static unsigned n = 0;
+    if (!n) {
+        const char* e = getenv("HEXL_HOST_THREADS");
+        n = e ? (unsigned)atoi(e) : std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        if (!n) n = 1;
+    }
+    return n;
+}
+
+static void parallel_for(size_t count, const std::function<void(size_t)>& fn) {
+    const unsigned nt = (unsigned)std::min<size_t>(host_threads(), count);
+    if (nt <= 1) { for (size_t i = 0; i < count; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < count;) fn(i); });
+    for (auto& t : th) t.join();
+}
+
+static int pipe_init(hexl_ctx* c) {
+    if (c->s_up) return 0;
+    HX_CHECK(hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+    HX_CHECK(hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HX_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+        HX_CHECK(hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming));
+        HX_CHECK(hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// pack(first, count, h_in)      fill the pinned input slab for items [first, first+count)
+// compute(count, d_in, d_out)   enqueue kernels on c->stream
+// unpack(first, count, h_out)   consume the pinned output slab
+// `shared_bytes` at the head of every input slab is filled by pack_shared once per slab (tables, moduli).
+struct PipeShape { size_t in1, out1, shared, sub; bool in_place; };
+
+static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
+                        const std::function<void(char*)>& pack_shared,
+                        const std::function<void(size_t, size_t, char*)>& pack,
+                        const std::function<int(size_t, char*, char*)>& compute,
+                        const std::function<void(size_t, size_t, const char*)>& unpack) {
+    int rc = pipe_init(c);
     if (rc) return rc;
-    return hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, bytes);
+    const size_t S = std::min(batch, sh.sub);
+    const size_t in_slab = (sh.shared + S * sh.in1 + 255) & ~size_t(255);
+    const size_t out_slab = sh.in_place ? 0 : ((S * sh.out1 + 255) & ~size_t(255));
+    const size_t set = in_slab + out_slab;
+    rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, 2 * set);
+    if (!rc) rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, 2 * set);
+    if (rc) return rc;
+    const size_t nsub = (batch + S - 1) / S;
+    auto h_in = [&](size_t k) { return (char*)c->h_stage + (k & 1) * set; };
+    auto d_in = [&](size_t k) { return (char*)c->d_stage + (k & 1) * set; };
+    auto h_out = [&](size_t k) { return sh.in_place ? h_in(k) + sh.shared : h_in(k) + in_slab; };
+    auto d_out = [&](size_t k) { return sh.in_place ? d_in(k) + sh.shared : d_in(k) + in_slab; };
+    for (size_t it = 0; it < nsub + 2; ++it) {
+        if (it >= 2) {                                            // drain sub-batch it-2 (frees slab set it&1)
+            const size_t k = it - 2, first = k * S, cnt = std::min(S, batch - first);
+            HX_CHECK(hipEventSynchronize(c->ev_down[k & 1]));
+            unpack(first, cnt, h_out(k));
+        }
+        if (it < nsub) {
+            const size_t first = it * S, cnt = std::min(S, batch - first);
+            if (sh.shared) pack_shared(h_in(it));
+            pack(first, cnt, h_in(it) + sh.shared);
+            HX_CHECK(hipMemcpyAsync(d_in(it), h_in(it), sh.shared + cnt * sh.in1, hipMemcpyHostToDevice, c->s_up));
+            HX_CHECK(hipEventRecord(c->ev_up[it & 1], c->s_up));
+            HX_CHECK(hipStreamWaitEvent(c->stream, c->ev_up[it & 1], 0));
+            rc = compute(cnt, d_in(it), d_out(it));
+            if (rc) return rc;
+            HX_CHECK(hipEventRecord(c->ev_comp[it & 1], c->stream));
+            HX_CHECK(hipStreamWaitEvent(c->s_down, c->ev_comp[it & 1], 0));
+            HX_CHECK(hipMemcpyAsync(h_out(it), d_out(it), cnt * (sh.in_place ? sh.in1 : sh.out1), hipMemcpyDeviceToHost,
+                                    c->s_down));
+            HX_CHECK(hipEventRecord(c->ev_down[it & 1], c->s_down));
+        }
+    }
+    return 0;
+}
+
+static size_t sub_batch_for(size_t bytes_per_item) {              // ~64 MB slabs keep all three stages busy
+    const char* e = getenv("HEXL_HOST_SUB_MB");
+    const size_t target = (e ? (size_t)atoi(e) : 64) << 20;
+    return std::max<size_t>(1, target / std::max<size_t>(1, bytes_per_item));
 }
 
 extern "C" int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch, const uint64_t* h_roots,
@@ -314,19 +410,13 @@ extern "C" int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch
     if (!c || !h_x || !h_roots || !h_precon || !supported_ntt_n(n)) return HEXL_E_BADARG;
     if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t one = n * 8, data = batch * one, tab = one;
-    int rc = stage_reserve(c, data + 2 * tab);
-    if (rc) return rc;
-    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    memcpy(h, h_roots, tab); memcpy(h + tab, h_precon, tab);
-    for (size_t b = 0; b < batch; ++b) memcpy(h + 2 * tab + b * one, h_x[b], one);
-    HX_CHECK(hipMemcpyAsync(d, h, data + 2 * tab, hipMemcpyHostToDevice, c->stream));
-    rc = hexl_ntt_fwd(c, (u64*)(d + 2 * tab), batch, (u64*)d, (u64*)(d + tab), q, n);
-    if (rc) return rc;
-    HX_CHECK(hipMemcpyAsync(h + 2 * tab, d + 2 * tab, data, hipMemcpyDeviceToHost, c->stream));
-    HX_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < batch; ++b) memcpy(h_x[b], h + 2 * tab + b * one, one);
-    return 0;
+    const size_t one = n * 8;
+    PipeShape sh{one, one, 2 * one, sub_batch_for(one), true};
+    return run_pipeline(c, batch, sh,
+        [&](char* h) { memcpy(h, h_roots, one); memcpy(h + one, h_precon, one); },
+        [&](size_t first, size_t cnt, char* h) { parallel_for(cnt, [&](size_t b) { memcpy(h + b * one, h_x[first + b], one); }); },
+        [&](size_t cnt, char* d, char* dout) { return hexl_ntt_fwd(c, (u64*)dout, cnt, (u64*)d, (u64*)(d + one), q, n); },
+        [&](size_t first, size_t cnt, const char* h) { parallel_for(cnt, [&](size_t b) { memcpy(h_x[first + b], h + b * one, one); }); });
 }
 
 extern "C" int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch, const uint64_t* h_ir,
@@ -334,19 +424,13 @@ extern "C" int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch
     if (!c || !h_x || !h_ir || !h_ip || !supported_ntt_n(n)) return HEXL_E_BADARG;
     if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t one = n * 8, data = batch * one, tab = one;
-    int rc = stage_reserve(c, data + 2 * tab);
-    if (rc) return rc;
-    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    memcpy(h, h_ir, tab); memcpy(h + tab, h_ip, tab);
-    for (size_t b = 0; b < batch; ++b) memcpy(h + 2 * tab + b * one, h_x[b], one);
-    HX_CHECK(hipMemcpyAsync(d, h, data + 2 * tab, hipMemcpyHostToDevice, c->stream));
-    rc = hexl_ntt_inv(c, (u64*)(d + 2 * tab), batch, (u64*)d, (u64*)(d + tab), q, inv_n, inv_n_w, n);
-    if (rc) return rc;
-    HX_CHECK(hipMemcpyAsync(h + 2 * tab, d + 2 * tab, data, hipMemcpyDeviceToHost, c->stream));
-    HX_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < batch; ++b) memcpy(h_x[b], h + 2 * tab + b * one, one);
-    return 0;
+    const size_t one = n * 8;
+    PipeShape sh{one, one, 2 * one, sub_batch_for(one), true};
+    return run_pipeline(c, batch, sh,
+        [&](char* h) { memcpy(h, h_ir, one); memcpy(h + one, h_ip, one); },
+        [&](size_t first, size_t cnt, char* h) { parallel_for(cnt, [&](size_t b) { memcpy(h + b * one, h_x[first + b], one); }); },
+        [&](size_t cnt, char* d, char* dout) { return hexl_ntt_inv(c, (u64*)dout, cnt, (u64*)d, (u64*)(d + one), q, inv_n, inv_n_w, n); },
+        [&](size_t first, size_t cnt, const char* h) { parallel_for(cnt, [&](size_t b) { memcpy(h_x[first + b], h + b * one, one); }); });
 }
 
 extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* h_out, const uint64_t* const* h_a,
@@ -355,25 +439,24 @@ extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* h_out, co
     if (!c || !h_out || !h_a || !h_b || !h_moduli) return HEXL_E_BADARG;
     if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
-    const size_t in1 = 2 * n_moduli * n * 8, out1 = 3 * n_moduli * n * 8, mod1 = n_moduli * 8;
-    const size_t in = batch * in1, outb = batch * out1, mod = batch * mod1;
-    const size_t mod_pad = (mod + 255) & ~size_t(255);
-    int rc = stage_reserve(c, 2 * in + outb + mod_pad);
-    if (rc) return rc;
-    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    for (size_t b = 0; b < batch; ++b) {
-        memcpy(h + b * mod1, h_moduli[b], mod1);
-        memcpy(h + mod_pad + b * in1, h_a[b], in1);
-        memcpy(h + mod_pad + in + b * in1, h_b[b], in1);
-    }
-    HX_CHECK(hipMemcpyAsync(d, h, mod_pad + 2 * in, hipMemcpyHostToDevice, c->stream));
-    rc = hexl_dyadic_multiply(c, (u64*)(d + mod_pad + 2 * in), (u64*)(d + mod_pad), (u64*)(d + mod_pad + in), batch, n,
-                              (u64*)d, n_moduli);
-    if (rc) return rc;
-    HX_CHECK(hipMemcpyAsync(h + mod_pad + 2 * in, d + mod_pad + 2 * in, outb, hipMemcpyDeviceToHost, c->stream));
-    HX_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < batch; ++b) memcpy(h_out[b], h + mod_pad + 2 * in + b * out1, out1);
-    return 0;
+    const size_t op1 = 2 * n_moduli * n * 8, out1 = 3 * n_moduli * n * 8, mod1 = n_moduli * 8;
+    const size_t in1 = 2 * op1 + ((mod1 + 15) & ~size_t(15));   // per item: [a | b | moduli(padded)]
+    PipeShape sh{in1, out1, 0, sub_batch_for(in1 + out1), false};
+    // layout inside a slab holding cnt items: a[cnt] | b[cnt] | moduli[cnt] (contiguous batches for the kernel);
+    // cnt*(2*op1 + mod1) <= cnt*in1 bytes, which is what the pipeline uploads
+    return run_pipeline(c, batch, sh, [](char*) {},
+        [&](size_t first, size_t cnt, char* h) {
+            parallel_for(cnt, [&](size_t k) {
+                memcpy(h + k * op1, h_a[first + k], op1);
+                memcpy(h + cnt * op1 + k * op1, h_b[first + k], op1);
+                memcpy(h + 2 * cnt * op1 + k * mod1, h_moduli[first + k], mod1);
+            });
+        },
+        [&](size_t cnt, char* d, char* dout) {
+            return hexl_dyadic_multiply(c, (u64*)dout, (u64*)d, (u64*)(d + cnt * op1), cnt, n, (u64*)(d + 2 * cnt * op1),
+                                        n_moduli);
+        },
+        [&](size_t first, size_t cnt, const char* h) { parallel_for(cnt, [&](size_t k) { memcpy(h_out[first + k], h + k * out1, out1); }); });
 }
 
 extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, const uint64_t* const* h_t_targets,
@@ -384,33 +467,33 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
     HX_CHECK(hipSetDevice(c->device));
     const size_t n = p->n, L = p->L;
     const size_t tt = L * n * 8, rs = 2 * tt;
-    int rc = stage_reserve(c, batch * (tt + rs));
-    if (rc) return rc;
-    char* h = (char*)c->h_stage; char* d = (char*)c->d_stage;
-    for (size_t b = 0; b < batch; ++b) memcpy(h + b * tt, h_t_targets[b], tt);       // copyKeySwitchBatch, fpga.cpp:542-555
-    HX_CHECK(hipMemcpyAsync(d, h, batch * tt, hipMemcpyHostToDevice, c->stream));
-    // Like the reference, the device produces the keyswitch output only (the kernel accumulates into a zeroed
-    // buffer) and the HOST adds it into the caller's result, object by object in submission order
+    PipeShape sh{tt, rs, 0, sub_batch_for(tt + rs), false};
+    // Like the reference, the device produces the keyswitch output only (the kernels accumulate into a zeroed
+    // buffer) and the HOST adds it into the caller's result in submission order
     // (FPGAObject_KeySwitch::fill_out_data, fpga.cpp:441-475). This keeps the semantics when several objects of a
-    // batch alias the same result array, as benchmark/bench_keyswitch.cpp:113-131 does.
-    HX_CHECK(hipMemsetAsync(d + batch * tt, 0, batch * rs, c->stream));
-    rc = hexl_keyswitch(p, (u64*)(d + batch * tt), (u64*)d, batch);
-    if (rc) return rc;
-    HX_CHECK(hipMemcpyAsync(h + batch * tt, d + batch * tt, batch * rs, hipMemcpyDeviceToHost, c->stream));
-    HX_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < batch; ++b) {
-        const u64* out = (const u64*)(h + batch * tt + b * rs);
-        u64* res = h_results[b];
+    // batch alias the same result array, as benchmark/bench_keyswitch.cpp:113-131 does; it also means `result`
+    // never crosses PCIe upwards.
+    auto add_into = [&](u64* res, const u64* out) {
         for (size_t k = 0; k < 2; ++k)
             for (size_t i = 0; i < L; ++i) {
                 const u64 q = p->moduli[i];
                 const u64* o = out + (k * L + i) * n;
                 u64* r = res + (k * L + i) * n;
-                for (size_t j = 0; j < n; ++j) {
-                    const u64 v = r[j] + o[j];
-                    r[j] = v >= q ? v - q : v;
-                }
+                for (size_t j = 0; j < n; ++j) { const u64 v = r[j] + o[j]; r[j] = v >= q ? v - q : v; }
             }
-    }
-    return 0;
+    };
+    return run_pipeline(c, batch, sh, [](char*) {},
+        [&](size_t first, size_t cnt, char* h) { parallel_for(cnt, [&](size_t b) { memcpy(h + b * tt, h_t_targets[first + b], tt); }); },
+        [&](size_t cnt, char* d, char* dout) {
+            HX_CHECK(hipMemsetAsync(dout, 0, cnt * rs, c->stream));
+            return hexl_keyswitch(p, (u64*)dout, (u64*)d, cnt);
+        },
+        [&](size_t first, size_t cnt, const char* h) {
+            bool distinct = true;                                   // aliased results must be added in order
+            for (size_t a = 0; a < cnt && distinct; ++a)
+                for (size_t b = a + 1; b < cnt; ++b)
+                    if (h_results[first + a] == h_results[first + b]) { distinct = false; break; }
+            if (distinct) parallel_for(cnt, [&](size_t b) { add_into(h_results[first + b], (const u64*)(h + b * rs)); });
+            else for (size_t b = 0; b < cnt; ++b) add_into(h_results[first + b], (const u64*)(h + b * rs));
+        });
 }

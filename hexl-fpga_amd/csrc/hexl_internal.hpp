@@ -31,6 +31,9 @@ struct hexl_ctx {
     // grow-only device scratch + pinned staging used by the *_host entry points
     void* d_stage = nullptr;  size_t d_stage_bytes = 0;
     void* h_stage = nullptr;  size_t h_stage_bytes = 0;
+    // host-pointer pipeline: copy streams + events (created lazily), see run_pipeline() in capi.hip
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     void* d_meta = nullptr;   size_t d_meta_bytes = 0;     // dyadic per-(item,modulus) constants
     void* d_ntt_tab = nullptr; size_t d_ntt_tab_bytes = 0;  // standalone NTT fast path: derived double tables + flag
     char name[256] = {0};

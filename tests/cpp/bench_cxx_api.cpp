@@ -1,0 +1,65 @@
+// bench_cxx_api.cpp -- end-to-end (host pointers, PCIe included) throughput of the reference's public C++ API on
+// libhexl-fpga.so, shaped like benchmark/bench_keyswitch.cpp:113-131 and bench_fwd_ntt.cpp:46-62: one warm-up
+// window, then timed worksize windows. Synthetic in-range data (splitmix). Prints keyswitch/s and NTT/s.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/hexl-fpga.h"
+#pragma GCC diagnostic ignored "-Wdeprecated-declarations"
+using namespace intel::hexl;
+typedef std::vector<uint64_t> vec;
+
+static uint64_t sm_state = 1;
+static uint64_t sm() { uint64_t z = (sm_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+    const size_t batch = argc > 1 ? atoi(argv[1]) : 256;
+    const uint64_t n = 16384, L = argc > 2 ? atoi(argv[2]) : 6, K = L + 1;
+    // the eight 52-bit primes of SURVEY 8c (GeneratePrimes(8, 51, 16384))
+    const uint64_t primes[8] = {2251799814045697ull, 2251799814799361ull, 2251799814930433ull, 2251799815094273ull,
+                                2251799815487489ull, 2251799815520257ull, 2251799816273921ull, 2251799816568833ull};
+    vec moduli(primes, primes + K), msf(K, 12345);
+    std::vector<vec> keys(L, vec(2 * K * n));
+    for (auto& k : keys) for (uint64_t kk = 0; kk < 2; ++kk) for (uint64_t i = 0; i < K; ++i) for (uint64_t j = 0; j < n; ++j) k[(kk * K + i) * n + j] = sm() % moduli[i];
+    std::vector<const uint64_t*> kp; for (auto& k : keys) kp.push_back(k.data());
+    std::vector<vec> t(batch, vec(L * n)), r(batch, vec(2 * L * n));
+    for (size_t b = 0; b < batch; ++b) {
+        for (uint64_t d = 0; d < L; ++d) for (uint64_t j = 0; j < n; ++j) t[b][d * n + j] = sm() % moduli[d];
+        for (uint64_t x = 0; x < 2 * L; ++x) for (uint64_t j = 0; j < n; ++j) r[b][x * n + j] = sm() % moduli[x % L];
+    }
+    acquire_FPGA_resources();
+    auto window = [&]() {
+        set_worksize_KeySwitch(batch);
+        for (size_t b = 0; b < batch; ++b) KeySwitch(r[b].data(), t[b].data(), n, L, K, L + 1, 2, moduli.data(), kp.data(), msf.data());
+        KeySwitchCompleted();
+    };
+    window();
+    const int iters = 5;
+    double t0 = now();
+    for (int i = 0; i < iters; ++i) window();
+    double dt = now() - t0;
+    std::printf("C++ API end-to-end keyswitch N=%lu L=%lu K=%lu batch=%zu: %.0f keyswitch/s (%.2f ms/window, %.2f GB/s over PCIe)\n",
+                n, L, K, batch, batch * iters / dt, dt / iters * 1e3, batch * iters * 3.0 * L * n * 8 / dt / 1e9);
+    // NTT: 4096 polynomials, one modulus (bench_fwd_ntt.cpp shape), proper tables not needed for timing
+    const size_t ws = 4096;
+    vec x(ws * n), roots(n), precon(n);
+    for (auto& v : x) v = sm() % moduli[0];
+    for (uint64_t j = 0; j < n; ++j) { roots[j] = sm() % moduli[0]; precon[j] = sm(); }
+    auto ntt_window = [&]() {
+        _set_worksize_NTT(ws);
+        for (size_t b = 0; b < ws; ++b) _NTT(x.data() + b * n, roots.data(), precon.data(), moduli[0], n);
+        _NTTCompleted();
+    };
+    ntt_window();
+    t0 = now();
+    for (int i = 0; i < 3; ++i) ntt_window();
+    dt = now() - t0;
+    std::printf("C++ API end-to-end fwd NTT N=%lu ws=%zu: %.0f NTT/s (%.2f ms/window, %.2f GB/s over PCIe)\n", n, ws, ws * 3 / dt,
+                dt / 3 * 1e3, ws * 3 * 2.0 * n * 8 / dt / 1e9);
+    release_FPGA_resources();
+    return 0;
+}

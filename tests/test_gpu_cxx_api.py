@@ -16,3 +16,14 @@ def test_cxx_api_driver():
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0 and "ALL PASSED" in out.stdout
+
+
+def test_cxx_api_driver_tiny_staging_slabs():
+    """same driver with 1 MiB staging slabs: every batch becomes many sub-batches with a ragged tail, exercising the
+    double-buffered H2D / kernel / D2H pipeline of the host-pointer entry points (capi.hip run_pipeline)"""
+    import os
+    exe = ROOT / "tests" / "cpp" / "test_cxx_api"
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HEXL_HOST_SUB_MB="1", HEXL_HOST_THREADS="3"))
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "ALL PASSED" in out.stdout
