@@ -232,11 +232,16 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
 extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
     if (!p) return 0;
     (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipDeviceSynchronize();
     if (p->d_mods) (void)hipFree(p->d_mods);
     if (p->d_tables) (void)hipFree(p->d_tables);
     if (p->d_keys) (void)hipFree(p->d_keys);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    for (int l = 0; l < 2; ++l) {
+        if (p->aux[l]) (void)hipStreamDestroy(p->aux[l]);
+        if (p->ev_done[l]) (void)hipEventDestroy(p->ev_done[l]);
+    }
+    if (p->ev_start) (void)hipEventDestroy(p->ev_start);
     if (p->d_mods_f64) (void)hipFree(p->d_mods_f64);
     if (p->d_tables_f64) (void)hipFree(p->d_tables_f64);
     if (p->d_keys_f64) (void)hipFree(p->d_keys_f64);

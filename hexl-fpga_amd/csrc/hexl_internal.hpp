@@ -78,9 +78,15 @@ struct hexl_ks_plan {
     KsModF64* d_mods_f64 = nullptr;   // [K]
     double* d_tables_f64 = nullptr;   // [K][4][n]
     double* d_keys_f64 = nullptr;     // [L][L+1][2][n]
-    // scratch for `cap` keyswitches in flight: c[cap][L][n], prod[cap][2][L][n], s[cap][2][n]
-    u64* d_scratch = nullptr;
+    // scratch for `cap` keyswitches per lane; two lanes (aux streams) work on alternating chunks so that kernels
+    // of different kinds -- FP64-bound transforms and the HBM-bound multiply-accumulate -- share the chip and one
+    // chunk's ragged last wave of workgroups is filled by the other's
+    u64* d_scratch = nullptr;         // [2 lanes][cap * scratch_words * n]
     size_t cap = 0;
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
+    hipStream_t cur = nullptr;        // stream the chunk being launched goes to
+    u64* cur_scratch = nullptr;
 };
 
 // launcher prototypes implemented per translation unit

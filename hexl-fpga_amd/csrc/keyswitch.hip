@@ -177,7 +177,7 @@ static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         attr_set = true;
     }
-    hipStream_t st = p->ctx->stream;
+    hipStream_t st = p->cur;
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1)
         hipLaunchKernelGGL((k_ks_intt<LOGN, LOGE>), dim3(a.nb * a.L), dim3(G::T), G::LDS_BYTES, st, a);
@@ -207,37 +207,60 @@ static size_t scratch_words(const hexl_ks_plan* p) {           // per instance, 
 }
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
     const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
-    return chunk * scratch_words(p) * p->n * sizeof(u64);
+    return 2 * chunk * scratch_words(p) * p->n * sizeof(u64);      // two lanes
 }
 
 int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
                         hipEvent_t* ev) {
     if (!batch) return 0;
     if (!p->have_keys) return HEXL_E_NOKEYS;
-    const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    // chunks alternate between two lanes; a batch that fits one chunk is still split in two when it is large
+    // enough to fill the chip twice, so the lanes always have something to overlap. Timing runs (ev) stay on one lane.
+    size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    const bool two_lanes = !ev && batch >= 64 && !(getenv("HEXL_KS_ONE_LANE") && atoi(getenv("HEXL_KS_ONE_LANE")) == 1);
+    if (two_lanes && batch <= chunk) chunk = (batch + 1) / 2;
+    const size_t lane_words = chunk * scratch_words(p) * p->n;
     if (p->cap < chunk) {
-        if (p->d_scratch) HX_CHECK(hipFree(p->d_scratch));
+        if (p->d_scratch) { HX_CHECK(hipDeviceSynchronize()); HX_CHECK(hipFree(p->d_scratch)); }
         p->d_scratch = nullptr; p->cap = 0;
-        HX_CHECK(hipMalloc((void**)&p->d_scratch, chunk * scratch_words(p) * p->n * sizeof(u64)));
+        HX_CHECK(hipMalloc((void**)&p->d_scratch, 2 * lane_words * sizeof(u64)));
         p->cap = chunk;
     }
+    if (!p->aux[0]) {
+        for (int l = 0; l < 2; ++l) {
+            HX_CHECK(hipStreamCreateWithFlags(&p->aux[l], hipStreamNonBlocking));
+            HX_CHECK(hipEventCreateWithFlags(&p->ev_done[l], hipEventDisableTiming));
+        }
+        HX_CHECK(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
+    }
+    hipStream_t user = p->ctx->stream;
+    const int lanes = two_lanes ? 2 : 1;
+    HX_CHECK(hipEventRecord(p->ev_start, user));                      // lanes start after everything queued so far
+    for (int l = 0; l < lanes; ++l) HX_CHECK(hipStreamWaitEvent(p->aux[l], p->ev_start, 0));
     const size_t n = p->n, L = p->L;
-    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
-        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
-        KsArgs a;
-        a.mods = p->d_mods; a.tables = p->d_tables; a.keys = p->d_keys;
-        a.c = p->d_scratch;
-        a.prod = a.c + p->cap * L * n;
-        a.s = a.prod + p->cap * 2 * L * n;
-        a.t_target = d_t_target + b0 * L * n;
-        a.result = d_result + b0 * 2 * L * n;
-        a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    // lane 1's first chunk is half-sized: the lanes then run out of phase, so one lane's HBM-bound kernels overlap
+    // the other's FP64-bound ones instead of both running the same kernel side by side
+    size_t ci = 0, nb = 0;
+    for (size_t b0 = 0; b0 < batch; b0 += nb, ++ci) {
+        const size_t want = (lanes == 2 && ci == 1) ? (chunk + 1) / 2 : chunk;
+        nb = (batch - b0 < want) ? batch - b0 : want;
+        const int lane = (int)(ci % lanes);
+        p->cur = p->aux[lane];
+        p->cur_scratch = p->d_scratch + size_t(lane) * p->cap * scratch_words(p) * n;
         int rc;
         if (p->use_f64) {
             rc = hx_launch_keyswitch_f64(p, d_result + b0 * 2 * L * n, d_t_target + b0 * L * n, nb, stage_mask, ev);
             if (rc) return rc;
             continue;
         }
+        KsArgs a;
+        a.mods = p->d_mods; a.tables = p->d_tables; a.keys = p->d_keys;
+        a.c = p->cur_scratch;
+        a.prod = a.c + p->cap * L * n;
+        a.s = a.prod + p->cap * 2 * L * n;
+        a.t_target = d_t_target + b0 * L * n;
+        a.result = d_result + b0 * 2 * L * n;
+        a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
         switch (p->logn) {
             case 10: rc = run_chunk<10, 4>(p, a, stage_mask, ev); break;
             case 11: rc = run_chunk<11, 5>(p, a, stage_mask, ev); break;
@@ -247,6 +270,10 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
             default: rc = HEXL_E_BADARG;
         }
         if (rc) return rc;
+    }
+    for (int l = 0; l < lanes; ++l) {                                  // the caller's stream continues after both lanes
+        HX_CHECK(hipEventRecord(p->ev_done[l], p->aux[l]));
+        HX_CHECK(hipStreamWaitEvent(user, p->ev_done[l], 0));
     }
     return 0;
 }

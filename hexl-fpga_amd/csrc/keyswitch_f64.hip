@@ -61,8 +61,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 
 // step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i) for slot != d (slot == d is written by k_ksf_intt), one
 // transform per workgroup, kept in the forward transform's register order ("B order", fully coalesced).
+// 1024-thread workgroups are capped at 96 VGPRs (5 waves/SIMD) so that one 256-thread k_ksf_mac workgroup of the
+// other lane can be co-resident on the CU: the HBM-bound multiply-accumulate then runs under the FP64-bound transforms.
 template <int LOGN, int LOGE, bool LAZY>
-__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGN - LOGE == 10) ? 5 : 1) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
@@ -202,7 +204,7 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
         if (rc) return rc;
         attr_set = true;
     }
-    hipStream_t st = p->ctx->stream;
+    hipStream_t st = p->cur;
     const u32 L = a.L, nb = a.nb;
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1)
@@ -230,7 +232,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     const size_t n = p->n, L = p->L;
     KsArgsF a;
     a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_f64;
-    a.c = (double*)p->d_scratch;
+    a.c = (double*)p->cur_scratch;
     a.u = a.c + p->cap * L * n;
     a.prod = a.u + p->cap * (L + 1) * L * n;
     a.s = a.prod + p->cap * 2 * (L + 1) * n;

@@ -295,6 +295,38 @@ float run(double* d, const double* w, const double* wp, int batch, const char* n
     return ms;
 }
 
+// two streams, each running the half-LDS kernel on half of the batch: workgroups of the two grids share CUs but
+// start at unrelated times, i.e. co-resident workgroups are NOT in lockstep. Compare with one stream.
+template <int LOGN, int LOGE, bool LAZY>
+void run_two_streams(double* d, const double* w, const double* wp, int batch) {
+    using G = Geom<LOGN, LOGE>;
+    Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
+    const int lb = (int)(HalfX<LOGN, LOGE, LAZY>::HALF_WORDS * 8 + 64);
+    auto kern = k_halfx<LOGN, LOGE, LAZY, 4, 0>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+    hipStream_t sa, sb; hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    hipEvent_t e0, e1, eb; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&eb);
+    for (int variant = 0; variant < 2; ++variant) {
+        hipDeviceSynchronize();
+        hipEventRecord(e0, sa);
+        hipStreamWaitEvent(sb, e0, 0);
+        for (int i = 0; i < 5; ++i) {
+            if (variant == 0) {
+                hipLaunchKernelGGL(kern, dim3(batch), dim3(G::T), lb, sa, d, w, wp, m);
+            } else {
+                hipLaunchKernelGGL(kern, dim3(batch / 2), dim3(G::T), lb, sa, d, w, wp, m);
+                hipLaunchKernelGGL(kern, dim3(batch / 2), dim3(G::T), lb, sb, d + size_t(batch / 2) * G::N, w, wp, m);
+            }
+        }
+        hipEventRecord(eb, sb);
+        hipStreamWaitEvent(sa, eb, 0);
+        hipEventRecord(e1, sa);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+        printf("E=%2d HALFX %s: %8.3f ms  %6.2f M NTT/s\n", 1 << LOGE, variant ? "two streams (desynchronised co-residents)" : "one stream", ms, batch / ms / 1e3);
+    }
+}
+
 int main() {
     const int N = 16384, batch = 2048;
     double *d, *w, *wp;
@@ -376,6 +408,8 @@ int main() {
     run_halfx<14, 5, false, 4, 3>(d, w, wp, batch, "strict, stagger 3");
     run_halfx<14, 5, false, 4, 5>(d, w, wp, batch, "strict, stagger 5");
     run_halfx<14, 5, true, 4, 3>(d, w, wp, batch, "lazy, stagger 3");
+    run_two_streams<14, 5, true>(d, w, wp, batch);
+    run_two_streams<14, 5, false>(d, w, wp, batch);
     run<14, 5, 0>(d, w, wp, batch, "full");
     run<14, 5, 9>(d, w, wp, batch, "no global load/store");
     run<14, 5, 15>(d, w, wp, batch, "ALU only");
