@@ -27,3 +27,14 @@ def test_cxx_api_driver_tiny_staging_slabs():
                          env=dict(os.environ, HEXL_HOST_SUB_MB="1", HEXL_HOST_THREADS="3"))
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0 and "ALL PASSED" in out.stdout
+
+
+def test_ckks_keyswitch_example():
+    """examples/ckks_keyswitch_example.cpp: real RLWE switching keys, _NTT/_INTT + KeySwitch through the public
+    API; decryption under the old key recovers t*s_new up to small noise (what the reference's SEAL test checks)"""
+    exe = ROOT / "examples" / "ckks_keyswitch_example"
+    if not exe.exists():
+        subprocess.run(["make", "-C", str(exe.parent)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-2000:], out.stderr[-1000:])
+    assert out.returncode == 0 and "EXAMPLE PASSED" in out.stdout
