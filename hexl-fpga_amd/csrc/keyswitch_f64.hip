@@ -61,10 +61,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 
 // step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i) for slot != d (slot == d is written by k_ksf_intt), one
 // transform per workgroup, kept in the forward transform's register order ("B order", fully coalesced).
-// 1024-thread workgroups are capped at 96 VGPRs (5 waves/SIMD) so that one 256-thread k_ksf_mac workgroup of the
-// other lane can be co-resident on the CU: the HBM-bound multiply-accumulate then runs under the FP64-bound transforms.
+// (Capping this kernel at 96 VGPRs so that a k_ksf_mac workgroup of the other lane could be co-resident was
+// measured: +12 % instructions, no throughput gain -- not done.)
 template <int LOGN, int LOGE, bool LAZY>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGN - LOGE == 10) ? 5 : 1) void k_ksf_ntt_up(KsArgsF a) {
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
