@@ -74,6 +74,28 @@ def time_ntt(hx, ctx, orc_mod, dev, batch, iters):
     return out
 
 
+def time_dyadic(hx, ctx, orc_mod, dev, batch=4096, n=8192, nm=4, iters=5):
+    """BASELINE config 3: dyadic_multiply n=8192, 4 RNS moduli, batch 4096 ciphertext pairs (56 B per coefficient-limb)"""
+    import torch
+    mod1 = np.array(orc_mod.primes(nm, 52, n), dtype=np.uint64)
+    rng = np.random.default_rng(0)
+    one = np.concatenate([rng.integers(0, int(m), n, dtype=np.uint64) for _ in range(2) for m in mod1])
+    a = hx.as_i64(one).to(dev).repeat(batch)
+    b = hx.as_i64(one[::-1].copy() % np.tile(np.repeat(mod1, n), 2)).to(dev).repeat(batch)
+    mod = hx.as_i64(np.tile(mod1, batch)).to(dev)
+    out = torch.empty(batch * 3 * nm * n, dtype=torch.int64, device=dev)
+    ctx.dyadic_multiply(out, a, b, mod, n, nm)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ctx.dyadic_multiply(out, a, b, mod, n, nm)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return {"ms_per_launch": ms, "items_per_s": batch / (ms * 1e-3), "alg_GBps": batch * 7 * nm * n * 8 / (ms * 1e-3) / 1e9}
+
+
 def cpu_baseline(orc_mod, case, budget_s=12.0):
     """the oracle (C restatement of the reference algorithm, single thread) timed on this host"""
     t, r = case.inputs(orc_mod, 0)
@@ -177,6 +199,7 @@ def main():
                  "device": ctx.describe()}
         if not a.no_extra:
             extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)
+            extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
             # the reference-representable shape 16384_6_7_7_2 (decomp 6, 7 key moduli)
             case6 = KsCase(orc_mod, N, 6, 7, seed=99)
             plan6 = hx.KeySwitchPlan(ctx, N, 6, 7, 7, 2, case6.moduli, case6.modswitch)
