@@ -114,7 +114,9 @@ extern "C" int hexl_dyadic_multiply(hexl_ctx* c, uint64_t* out, const uint64_t* 
 static u32 ks_loge(u32 logn, bool f64) { return logn <= 10 ? 4 : (f64 && logn == 14 ? 4 : 5); }
 static u32 ks_idxB(u32 logn, u32 loge, u32 r, u32 tid) {
     const u32 P = (logn + loge - 1) / loge, KL = logn - (P - 1) * loge;
-    return ((r >> KL) << (logn - loge + KL)) + (tid << KL) + (r & ((1u << KL) - 1));
+    const u32 WB = logn - loge < 6 ? logn - loge : 6;          // mirrors Geom::idxB (ntt_core.hpp)
+    const u32 grp = ((tid >> WB) << (loge - KL + WB)) + ((r >> KL) << WB) + (tid & ((1u << WB) - 1));
+    return (grp << KL) + (r & ((1u << KL) - 1));
 }
 // perm[pos] = natural coefficient index stored at position pos of a "B order" ([r][tid]) limb
 static std::vector<u32> ks_perm(u32 logn, u32 loge) {

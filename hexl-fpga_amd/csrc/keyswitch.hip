@@ -65,8 +65,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_intt(KsArgs a) {
     u64 v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = src[G::idxB(r, tid)];
-    WgNtt<LOGN, LOGE>::inverse(v, lds, tid, tb + 2 * G::N, tb + 3 * G::N, md.q, md.inv_n, md.inv_n_p, md.inv_n_w,
-                               md.inv_n_w_p);
+    WgNtt<LOGN, LOGE>::template inverse<true>(v, lds, tid, tb + 2 * G::N, tb + 3 * G::N, md.q, md.inv_n, md.inv_n_p,
+                                              md.inv_n_w, md.inv_n_w_p);
     u64* dst = a.c + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = v[r];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_moddown(KsArgs a) {
     u64 v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = barrett64(sk[G::idxA(r, tid)] + md.fix, q, md.qbarr);   // intt2_redu.hpp:49-51
-    W::forward_lazy(v, lds, tid, tb, tb + G::N, q);
+    W::template forward_lazy<true>(v, lds, tid, tb, tb + G::N, q);
     W::final_reduce(v, q);
 
     const u64* pk = a.prod + ((size_t(b) * 2 + k) * L + i) * G::N;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) ud[r * G::T + tid] = v[r];
     }
-    WgNttF64<LOGN, LOGE, LAZY>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
     double* dst = a.c + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = hxf::lift(v[r], md.m);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(cd[G::idxA(r, tid)], m);          // c_d mod q_i (intt1_redu.hpp:36-42)
     const double* tb = a.tables + size_t(i) * 4 * G::N;
-    W::forward(v, ldsd, tid, tb, tb + G::N, m);
+    W::template forward<true>(v, ldsd, tid, tb, tb + G::N, m);
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = v[r];
 }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = src[r * G::T + tid];
-    WgNttF64<LOGN, LOGE, LAZY>::inverse(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
+    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
     double* dst = a.s + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r)                                // intt2_redu.hpp:25,43
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(sk[G::idxA(r, tid)] + md.fix, m);   // intt2_redu.hpp:49-51
-    W::forward(v, ldsd, tid, tb, tb + G::N, m);
+    W::template forward<true>(v, ldsd, tid, tb, tb + G::N, m);
 
     const double* pk = a.prod + ((size_t(b) * 2 + k) * (L + 1) + i) * G::N;
     u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;

@@ -38,6 +38,35 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     wp[i] = c / pd;
 }
 
+// Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
+// FP64 code (inlined, the allocator spilled ~100 VGPRs on the fast path).
+template <int LOGN, int LOGE>
+__device__ __attribute__((noinline)) void slow_fwd(u64* px, u64* lds, const u64* roots, const u64* precon, u64 q) {
+    using G = Geom<LOGN, LOGE>;
+    const int tid = threadIdx.x;
+    u64 v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = px[G::idxA(r, tid)];
+    __syncthreads();                           // every wave holds its input before anyone overwrites it in place
+    WgNtt<LOGN, LOGE>::forward_lazy(v, lds, tid, roots, precon, q);
+    WgNtt<LOGN, LOGE>::final_reduce(v, q);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = v[r];
+}
+template <int LOGN, int LOGE>
+__device__ __attribute__((noinline)) void slow_inv(u64* px, u64* lds, const u64* iroots, const u64* iprecon, u64 q,
+                                                   u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p) {
+    using G = Geom<LOGN, LOGE>;
+    const int tid = threadIdx.x;
+    u64 v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = px[G::idxB(r, tid)];
+    __syncthreads();
+    WgNtt<LOGN, LOGE>::inverse(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
+}
+
 template <int LOGN, int LOGE, bool LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restrict__ x, const u64* __restrict__ roots,
                                                                   const u64* __restrict__ precon, u64 q,
@@ -50,26 +79,27 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     const u32 p = blockIdx.x;
     if (p >= batch) return;
     u64* px = x + size_t(p) * G::N;
-    u64 v[G::E];
     const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
+    const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
+    double f[G::E];
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) { v[r] = px[G::idxA(r, tid)]; out_of_range |= v[r] >= limit; }
+    for (int r = 0; r < G::E; ++r) {
+        const u64 raw = px[G::idxA(r, tid)];
+        out_of_range |= raw >= limit;
+        f[r] = hxf::reduce(hxf::to_f64(raw), m);
+    }
+    // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
+    // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
+    // in lockstep). The input is still intact in memory for the integer fallback.
+    WgNttF64<LOGN, LOGE, LAZY>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);
     if (!slow) {
-        const Mod m{(double)q, 1.0 / (double)q};
-        double f[G::E];
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) f[r] = hxf::reduce(hxf::to_f64(v[r]), m);
-        WgNttF64<LOGN, LOGE, LAZY>::forward(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::from_f64(hxf::lift(f[r], m));
+        for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
     } else {
-        WgNtt<LOGN, LOGE>::forward_lazy(v, lds, tid, roots, precon, q);
-        WgNtt<LOGN, LOGE>::final_reduce(v, q);
+        slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
     }
-#pragma unroll
-    for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = v[r];
 }
 
 template <int LOGN, int LOGE, bool LAZY>
@@ -85,25 +115,24 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
     const u32 p = blockIdx.x;
     if (p >= batch) return;
     u64* px = x + size_t(p) * G::N;
-    u64 v[G::E];
     const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
+    const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
+    double f[G::E];
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) { v[r] = px[G::idxB(r, tid)]; out_of_range |= v[r] >= limit; }
-    const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);
-    if (!slow) {
-        const Mod m{(double)q, 1.0 / (double)q};
-        double f[G::E];
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) f[r] = hxf::reduce(hxf::to_f64(v[r]), m);
-        WgNttF64<LOGN, LOGE, LAZY>::inverse(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::from_f64(hxf::lift(f[r], m));
-    } else {
-        WgNtt<LOGN, LOGE>::inverse(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+    for (int r = 0; r < G::E; ++r) {
+        const u64 raw = px[G::idxB(r, tid)];
+        out_of_range |= raw >= limit;
+        f[r] = hxf::reduce(hxf::to_f64(raw), m);
     }
+    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);
+    const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);      // see k_ntt_fwd_x
+    if (!slow) {
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
+        for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+    } else {
+        slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+    }
 }
 
 static bool fast_path_enabled() {
@@ -142,7 +171,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd(u64* __restrict_
         u64 v[G::E];
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = px[G::idxA(r, tid)];
-        WgNtt<LOGN, LOGE>::forward_lazy(v, lds, tid, roots, precon, q);
+        WgNtt<LOGN, LOGE>::template forward_lazy<true>(v, lds, tid, roots, precon, q);
         WgNtt<LOGN, LOGE>::final_reduce(v, q);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = v[r];
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv(u64* __restrict_
         u64 v[G::E];
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = px[G::idxB(r, tid)];
-        WgNtt<LOGN, LOGE>::inverse(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        WgNtt<LOGN, LOGE>::template inverse<true>(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
     }
@@ -185,7 +214,9 @@ u32 hx_loge_for(u32 logn) {
 u32 hx_idxB(u32 logn, u32 r, u32 tid) {
     const u32 loge = hx_loge_for(logn);
     const u32 P = (logn + loge - 1) / loge, KL = logn - (P - 1) * loge;
-    return ((r >> KL) << (logn - loge + KL)) + (tid << KL) + (r & ((1u << KL) - 1));
+    const u32 WB = logn - loge < 6 ? logn - loge : 6;          // mirrors Geom::idxB (ntt_core.hpp)
+    const u32 grp = ((tid >> WB) << (loge - KL + WB)) + ((r >> KL) << WB) + (tid & ((1u << WB) - 1));
+    return (grp << KL) + (r & ((1u << KL) - 1));
 }
 
 template <int LOGN, int LOGE>

@@ -84,16 +84,29 @@ struct Geom {
     static constexpr int LDS_WORDS = N + (N >> 4) + ((N >> 9) << 4);
     static constexpr size_t LDS_BYTES = size_t(LDS_WORDS) * 8;
 
+    static constexpr int LOGT = LOGN - LOGE;
+    static constexpr int WB = LOGT < 6 ? LOGT : 6;         // thread-index bits that are lane bits
+
     __device__ static __forceinline__ int pad(int idx) { return idx + (idx >> 4) + ((idx >> 9) << 4); }
     __device__ static __forceinline__ int idxA(int r, int tid) { return r * T + tid; }
+    // partial pass ("B order"): a thread owns NG groups of 2^KL adjacent coefficients. Lanes sit on index bits
+    // [KL, KL+6), the group number above them and the wave number on the top bits -- the same top bits a wave
+    // owns in every full pass with LO <= 6, so the re-deals between those passes never leave the wave.
+    __device__ static __forceinline__ int grpB(int grp, int tid) {            // coefficient index >> KL
+        return ((tid >> WB) << (LOGE - KL + WB)) + (grp << WB) + (tid & ((1 << WB) - 1));
+    }
     __device__ static __forceinline__ int idxB(int r, int tid) {
-        return ((r >> KL) << (LOGN - LOGE + KL)) + (tid << KL) + (r & ((1 << KL) - 1));
+        return (grpB(r >> KL, tid) << KL) + (r & ((1 << KL) - 1));
     }
     // full pass whose LOGE active index bits start at bit LO
     template <int LO>
     __device__ static __forceinline__ int idxF(int r, int tid) {
         return ((tid >> LO) << (LO + LOGE)) + (r << LO) + (tid & ((1 << LO) - 1));
     }
+    // a re-deal between two ownership maps whose upper one is idxF<LO> moves data only inside a wave when the
+    // wave-number bits of the thread index map to the same coefficient bits on both sides
+    template <int LO>
+    static constexpr bool wave_private = (LOGT <= 6) || (LO <= 6);
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -178,13 +191,36 @@ __device__ __forceinline__ void redeal(u64 (&v)[G::E], u64* lds, int tid, FromId
     __syncthreads();
 }
 
+// compiler-only ordering point for LDS traffic that stays inside one wave (the hardware executes a wave's LDS
+// instructions in order; this keeps the compiler from moving reads above the writes of other lanes)
+__device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }
+
+// Re-deal with the minimum of synchronisation. PRIVATE: every coefficient stays inside its wave -> no
+// s_barrier at all, the waves of the workgroup drift apart and cover each other's LDS/memory latency.
+// Otherwise one barrier between writes and reads, preceded (LEAD) by one that waits for earlier readers of
+// the words about to be overwritten. No trailing barrier: after a cross-wave exchange a wave only ever
+// touches its own block until the next cross-wave exchange, which brings its own LEAD barrier.
+template <class G, bool PRIVATE, bool LEAD, class V, class FromIdx, class ToIdx>
+__device__ __forceinline__ void redeal_x(V (&v)[G::E], V* lds, int tid, FromIdx from, ToIdx to) {
+    if constexpr (PRIVATE) wave_fence();
+    else if constexpr (LEAD) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) lds[G::pad(from(r, tid))] = v[r];
+    if constexpr (PRIVATE) wave_fence();
+    else __syncthreads();
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = lds[G::pad(to(r, tid))];
+    if constexpr (PRIVATE) wave_fence();
+}
+
 template <int LOGN, int LOGE>
 struct WgNtt {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
 
     // ---- forward: v in A layout on entry, B layout on exit; values in [0,4q) (lazy) ---------
-    template <int PASS>
+    // FRESH: no other LDS traffic of this workgroup can still be in flight (single-transform kernels)
+    template <int PASS, bool FRESH = false>
     __device__ static __forceinline__ void fwd_pass(u64 (&v)[E], u64* lds, int tid,
                                                     const u64* roots, const u64* precon, u64 q, u64 twoq) {
         if constexpr (PASS < G::P - 1) {
@@ -194,15 +230,17 @@ struct WgNtt {
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             fwd_stages<E, 0, LOGE, PASS * LOGE + 1>(v, Gp, roots, precon, q, twoq);
             // hand over to the next pass's ownership
+            constexpr bool PRIV = G::template wave_private<LO>;
+            constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
-                redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                          [](int r, int t) { return G::template idxF<LO2>(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                                        [](int r, int t) { return G::template idxF<LO2>(r, t); });
             } else {
-                redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                          [](int r, int t) { return G::idxB(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                                        [](int r, int t) { return G::idxB(r, t); });
             }
-            fwd_pass<PASS + 1>(v, lds, tid, roots, precon, q, twoq);
+            fwd_pass<PASS + 1, FRESH>(v, lds, tid, roots, precon, q, twoq);
         } else {
             // partial pass: NG groups of 2^KL contiguous words
             fwd_last<0>(v, tid, roots, precon, q, twoq);
@@ -212,14 +250,15 @@ struct WgNtt {
     __device__ static __forceinline__ void fwd_last(u64 (&v)[E], int tid, const u64* roots,
                                                     const u64* precon, u64 q, u64 twoq) {
         if constexpr (GRP < G::NG) {
-            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            const u32 Gbits = u32(G::grpB(GRP, tid));
             fwd_stages<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1>(v, Gbits, roots, precon, q, twoq);
             fwd_last<GRP + 1>(v, tid, roots, precon, q, twoq);
         }
     }
+    template <bool FRESH = false>
     __device__ static __forceinline__ void forward_lazy(u64 (&v)[E], u64* lds, int tid, const u64* roots,
                                                         const u64* precon, u64 q) {
-        fwd_pass<0>(v, lds, tid, roots, precon, q, q << 1);
+        fwd_pass<0, FRESH>(v, lds, tid, roots, precon, q, q << 1);
     }
     // fwd_ntt.cpp:369-384
     __device__ static __forceinline__ void final_reduce(u64 (&v)[E], u64 q) {
@@ -234,38 +273,41 @@ struct WgNtt {
                                                      const u64* iprecon, u64 q, u64 twoq, u64 a, u64 ap,
                                                      u64 b, u64 bp) {
         if constexpr (GRP < G::NG) {
-            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            const u32 Gbits = u32(G::grpB(GRP, tid));
             inv_stages<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1)>(v, Gbits, iroots, iprecon, q,
                                                                           twoq, a, ap, b, bp);
             inv_first<GRP + 1>(v, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
         }
     }
     // PASS counts the full passes after the partial one: active bits [KL + PASS*LOGE, +LOGE)
-    template <int PASS>
+    template <int PASS, bool FRESH = false>
     __device__ static __forceinline__ void inv_pass(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
                                                     const u64* iprecon, u64 q, u64 twoq, u64 a, u64 ap,
                                                     u64 b, u64 bp) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
+            constexpr bool PRIV = G::template wave_private<LO>;
+            constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PASS == 0) {
-                redeal<G>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
-                          [](int r, int t) { return G::template idxF<LO>(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
+                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
             } else {
                 constexpr int LOP = LO - LOGE;
-                redeal<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
-                          [](int r, int t) { return G::template idxF<LO>(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
+                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
             }
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iroots, iprecon, q, twoq, a, ap, b, bp);
-            inv_pass<PASS + 1>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
+            inv_pass<PASS + 1, FRESH>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
         }
     }
+    template <bool FRESH = false>
     __device__ static __forceinline__ void inverse(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
                                                    const u64* iprecon, u64 q, u64 inv_n, u64 inv_n_p,
                                                    u64 inv_n_w, u64 inv_n_w_p) {
         const u64 twoq = q << 1;
         inv_first<0>(v, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
-        inv_pass<0>(v, lds, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        inv_pass<0, FRESH>(v, lds, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
     }
 };
 

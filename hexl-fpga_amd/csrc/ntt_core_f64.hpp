@@ -80,8 +80,8 @@ struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
 
-    // forward: A layout in, B layout out, all values centred
-    template <int PASS>
+    // forward: A layout in, B layout out, all values centred. FRESH as in ntt_core.hpp (single-transform kernels).
+    template <int PASS, bool FRESH = false>
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
                                                     const double* wp, const Mod m) {
         if constexpr (PASS < G::P - 1) {
@@ -89,15 +89,17 @@ struct WgNttF64 {
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
+            constexpr bool PRIV = G::template wave_private<LO>;
+            constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
-                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                              [](int r, int t) { return G::template idxF<LO2>(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                                        [](int r, int t) { return G::template idxF<LO2>(r, t); });
             } else {
-                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                              [](int r, int t) { return G::idxB(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
+                                        [](int r, int t) { return G::idxB(r, t); });
             }
-            fwd_pass<PASS + 1>(v, lds, tid, w, wp, m);
+            fwd_pass<PASS + 1, FRESH>(v, lds, tid, w, wp, m);
         } else {
             fwd_last<0>(v, tid, w, wp, m);
         }
@@ -106,14 +108,15 @@ struct WgNttF64 {
     __device__ static __forceinline__ void fwd_last(double (&v)[E], int tid, const double* w, const double* wp,
                                                     const Mod m) {
         if constexpr (GRP < G::NG) {
-            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            const u32 Gbits = u32(G::grpB(GRP, tid));
             fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, LOGN, LAZY>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1>(v, tid, w, wp, m);
         }
     }
+    template <bool FRESH = false>
     __device__ static __forceinline__ void forward(double (&v)[E], double* lds, int tid, const double* w,
                                                    const double* wp, const Mod m) {
-        fwd_pass<0>(v, lds, tid, w, wp, m);
+        fwd_pass<0, FRESH>(v, lds, tid, w, wp, m);
     }
     // every pass except the last (partial) one, ending with the re-deal into B layout; fwd_last<0> finishes.
     // Lets a persistent kernel slot the next polynomial's loads between the two.
@@ -142,33 +145,36 @@ struct WgNttF64 {
     __device__ static __forceinline__ void inv_first(double (&v)[E], int tid, const double* iw, const double* iwp,
                                                      const Mod m, const InvScale sc) {
         if constexpr (GRP < G::NG) {
-            const u32 Gbits = (u32(GRP) << (LOGN - LOGE)) + u32(tid);
+            const u32 Gbits = u32(G::grpB(GRP, tid));
             inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY>(v, Gbits, iw, iwp, m, sc);
             inv_first<GRP + 1>(v, tid, iw, iwp, m, sc);
         }
     }
-    template <int PASS>
+    template <int PASS, bool FRESH = false>
     __device__ static __forceinline__ void inv_pass(double (&v)[E], double* lds, int tid, const double* iw,
                                                     const double* iwp, const Mod m, const InvScale sc) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
+            constexpr bool PRIV = G::template wave_private<LO>;
+            constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PASS == 0) {
-                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
-                              [](int r, int t) { return G::template idxF<LO>(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
+                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
             } else {
                 constexpr int LOP = LO - LOGE;
-                redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
-                              [](int r, int t) { return G::template idxF<LO>(r, t); });
+                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
+                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
             }
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY>(v, Gp, iw, iwp, m, sc);
-            inv_pass<PASS + 1>(v, lds, tid, iw, iwp, m, sc);
+            inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc);
         }
     }
+    template <bool FRESH = false>
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
                                                    const double* iwp, const Mod m, const InvScale sc) {
         inv_first<0>(v, tid, iw, iwp, m, sc);
-        inv_pass<0>(v, lds, tid, iw, iwp, m, sc);
+        inv_pass<0, FRESH>(v, lds, tid, iw, iwp, m, sc);
     }
 };
 

@@ -382,6 +382,8 @@ int main() {
     run_persist<14, 4, true>(d, w, wp, batch, 256);
     run_persist<14, 4, true>(d, w, wp, batch, 512);
     run_halfx<14, 4, true, 1>(d, w, wp, batch, "E=16 lazy half-exchange, 1 WG");
+    run_halfx<14, 4, true, 8>(d, w, wp, batch, "E=16 lazy half-exchange, 64 VGPR cap (2 WG/CU)");
+    run_halfx<14, 4, true, 8, 3>(d, w, wp, batch, "E=16 lazy half-exch, 64 VGPR, stagger 3");
     {   // correctness of the half-exchange kernel vs the single one (E=32 outputs are in the E=32 B order: compare sorted sums)
         std::vector<double> r1(size_t(4) * N), r2(size_t(4) * N);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
