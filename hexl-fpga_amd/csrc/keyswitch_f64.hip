@@ -85,7 +85,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(cd[G::idxA(r, tid)], m);          // c_d mod q_i (intt1_redu.hpp:36-42)
     const double* tb = a.tables + size_t(i) * 4 * G::N;
-    W::template forward<true>(v, ldsd, tid, tb, tb + G::N, m);
+    // no final range reduction (LAZY): |u| <= 1.91p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
+    // |result| < p); tests/cpp/f64_selftest.cpp replays exactly this chain against 128-bit integers
+    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = v[r];
 }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(sk[G::idxA(r, tid)] + md.fix, m);   // intt2_redu.hpp:49-51
-    W::template forward<true>(v, ldsd, tid, tb, tb + G::N, m);
+    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);      // |w| <= 1.91p: |prod - w| <= 2.41p below
 
     const double* pk = a.prod + ((size_t(b) * 2 + k) * (L + 1) + i) * G::N;
     u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;

@@ -81,7 +81,10 @@ struct WgNttF64 {
     static constexpr int E = G::E;
 
     // forward: A layout in, B layout out, all values centred. FRESH as in ntt_core.hpp (single-transform kernels).
-    template <int PASS, bool FRESH = false>
+    // FINAL = false (LAZY only): the range reduction after the last stage is left to the consumer, outputs are
+    // then bounded by 1.91p instead of p/2 (two unreduced stages after the reduction at the last multiple of three;
+    // f64_arith.hpp) -- mul_mod and mul_shoup of the mod-up / mod-down epilogues accept that.
+    template <int PASS, bool FRESH = false, bool FINAL = true>
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
                                                     const double* wp, const Mod m) {
         if constexpr (PASS < G::P - 1) {
@@ -99,24 +102,26 @@ struct WgNttF64 {
                 redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
                                         [](int r, int t) { return G::idxB(r, t); });
             }
-            fwd_pass<PASS + 1, FRESH>(v, lds, tid, w, wp, m);
+            fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m);
         } else {
-            fwd_last<0>(v, tid, w, wp, m);
+            fwd_last<0, FINAL>(v, tid, w, wp, m);
         }
     }
-    template <int GRP>
+    template <int GRP, bool FINAL = true>
     __device__ static __forceinline__ void fwd_last(double (&v)[E], int tid, const double* w, const double* wp,
                                                     const Mod m) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, LOGN, LAZY>(v, Gbits, w, wp, m);
-            fwd_last<GRP + 1>(v, tid, w, wp, m);
+            // LOGN = 0 tells the stage loop that no stage is the last one
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY>(v, Gbits, w, wp, m);
+            fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }
-    template <bool FRESH = false>
+    template <bool FRESH = false, bool FINAL = true>
     __device__ static __forceinline__ void forward(double (&v)[E], double* lds, int tid, const double* w,
                                                    const double* wp, const Mod m) {
-        fwd_pass<0, FRESH>(v, lds, tid, w, wp, m);
+        static_assert(G::P > 1, "single-pass geometries are not used");
+        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m);
     }
     // every pass except the last (partial) one, ending with the re-deal into B layout; fwd_last<0> finishes.
     // Lets a persistent kernel slot the next polynomial's loads between the two.

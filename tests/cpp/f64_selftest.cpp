@@ -126,6 +126,39 @@ static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
         }
     }
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "lazy fwd n=%lu p=%lu i=%lu", n, p, i);
+    {   // the same schedule WITHOUT the reduction after the last stage (mod-up / mod-down kernels), followed by its
+        // two consumers: mul_mod with a centred key (k_ksf_mac) and mul_shoup of (prod - w) (k_ksf_moddown)
+        std::vector<double> u(n);
+        for (uint64_t i = 0; i < n; ++i) u[i] = centre(x[i]);
+        int s2 = 1;
+        for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s2) {
+            const bool red = hxf::lazy_fwd_reduce_after(s2, 0);
+            for (uint64_t i = 0; i < mm; ++i) {
+                const double w = centre(roots[mm + i]), wp = w / (double)p;
+                for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                    if (red) hxf::ct_bfly(u[j], u[j + t], w, wp, m); else hxf::ct_bfly_lazy(u[j], u[j + t], w, wp, m);
+                    track(u[j]); track(u[j + t]);
+                }
+            }
+        }
+        std::vector<uint64_t> key(n), pr(n);
+        orc_fill_splitmix(key.data(), n, p ^ 0x5151, p);
+        orc_fill_splitmix(pr.data(), n, p ^ 0x7373, p);
+        const uint64_t msf = adversarial ? p / 2 + 1 : key[0];
+        const double msf_c = centre(msf), msf_p = msf_c / (double)p;
+        for (uint64_t i = 0; i < n; ++i) {
+            CHECK(hxf::from_f64(hxf::lift(hxf::reduce(u[i], m), m)) == ref[i], "unreduced tail n=%lu p=%lu i=%lu", n, p, i);
+            const uint64_t kv = adversarial ? ((i & 1) ? p / 2 : p / 2 + 1) : key[i];
+            const double prod = hxf::mul_mod(u[i], centre(kv), m);
+            track(prod);
+            CHECK(hxf::from_f64(hxf::lift(hxf::reduce(prod, m), m)) == orc_mulmod(ref[i], kv, p), "mac on unreduced u n=%lu p=%lu i=%lu", n, p, i);
+            const double in = centre(pr[i]) - u[i];
+            const double out = hxf::mul_shoup(in, msf_c, msf_p, m);
+            track(in); track(out);
+            const uint64_t diff = (pr[i] + p - ref[i]) % p;
+            CHECK(hxf::from_f64(hxf::lift(hxf::reduce(out, m), m)) == orc_mulmod(diff, msf, p), "moddown on unreduced w n=%lu p=%lu i=%lu", n, p, i);
+        }
+    }
     // inverse, last stage fused with the scaling exactly as inv_stages_f64 does
     ref = x; orc_ks_intt(ref.data(), n, p, inv0);
     for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
