@@ -70,12 +70,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
-    const u32 item = xcd_item_f(blockIdx.x, gridDim.x);           // pair*nb + b : one XCD works on one (slot, d) pair
-    const u32 pr = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - pr * a.nb;
-    // pairs with slot != d: L-1 per ordinary slot, then L for the special-prime slot
-    u32 slot, d;
-    if (pr < L * (L - 1)) { slot = pr / (L - 1); d = pr - slot * (L - 1); d += (d >= slot); }
-    else                  { slot = L; d = pr - L * (L - 1); }
+    // (b*L + d)*L + s, XCD-contiguous: the L transforms that read the same c_d run back to back on one XCD, so c_d
+    // comes from HBM once and from that XCD's L2 afterwards
+    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_f(blockIdx.x, gridDim.x));
+    const u32 bd = item / L, sidx = item - bd * L;
+    const u32 b = bd / L, d = bd - b * L;
+    const u32 slot = sidx + (sidx >= d ? 1u : 0u);                // 0..L without d; slot L is the special prime
     const u32 i = slot < L ? slot : a.K - 1;
     const KsModF64 md = a.mods[i];
     const Mod m = md.m;
@@ -162,9 +162,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
-    const u32 item = xcd_item_f(blockIdx.x, gridDim.x);           // (i*2 + k)*nb + b
-    const u32 ik = __builtin_amdgcn_readfirstlane(item / a.nb), b = item - ik * a.nb;
-    const u32 i = ik >> 1, k = ik & 1;
+    // (b*2 + k)*L + i, XCD-contiguous: the L transforms that read the same s'_k run back to back on one XCD
+    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_f(blockIdx.x, gridDim.x));
+    const u32 bk = item / L, i = item - bk * L;
+    const u32 b = bk >> 1, k = bk & 1;
     const KsModF64 md = a.mods[i];
     const Mod m = md.m;
     const double* tb = a.tables + size_t(i) * 4 * G::N;
