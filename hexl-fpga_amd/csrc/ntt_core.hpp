@@ -200,16 +200,21 @@ __device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }
 // Otherwise one barrier between writes and reads, preceded (LEAD) by one that waits for earlier readers of
 // the words about to be overwritten. No trailing barrier: after a cross-wave exchange a wave only ever
 // touches its own block until the next cross-wave exchange, which brings its own LEAD barrier.
+// Every ownership map is "thread part OR register part" on disjoint coefficient bits, and Geom::pad only shifts
+// and adds, so pad(at(r, tid)) = pad(at(0, tid)) + pad(at(r, 0)): one address per side plus compile-time offsets
+// (the LDS instructions' immediate field) instead of ~7 integer instructions per coefficient.
 template <class G, bool PRIVATE, bool LEAD, class V, class FromIdx, class ToIdx>
 __device__ __forceinline__ void redeal_x(V (&v)[G::E], V* lds, int tid, FromIdx from, ToIdx to) {
+    V* const wr = lds + G::pad(from(0, tid));
+    V* const rd = lds + G::pad(to(0, tid));
     if constexpr (PRIVATE) wave_fence();
     else if constexpr (LEAD) __syncthreads();
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) lds[G::pad(from(r, tid))] = v[r];
+    for (int r = 0; r < G::E; ++r) wr[G::pad(from(r, 0))] = v[r];
     if constexpr (PRIVATE) wave_fence();
     else __syncthreads();
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) v[r] = lds[G::pad(to(r, tid))];
+    for (int r = 0; r < G::E; ++r) v[r] = rd[G::pad(to(r, 0))];
     if constexpr (PRIVATE) wave_fence();
 }
 

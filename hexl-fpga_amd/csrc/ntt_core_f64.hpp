@@ -12,9 +12,15 @@ namespace hx {
 
 using hxf::Mod;
 
+// Twiddle tables are written by the host before any kernel runs and never change: reading them through the
+// constant address space tells the compiler so. Without it, a kernel that also stores to global memory inside a
+// loop (k_ksf_up) loses its scalar (s_load) twiddle fetches for the wave-uniform passes -- the stores might alias.
+typedef const __attribute__((address_space(4))) double* ctw_t;
+
 // LAZY (moduli <= hxf::LAZY_MAX_MODULUS): butterflies skip the range reduction except after every third
 // global stage and after the last one (bounds in f64_arith.hpp). LOGN is only needed to find the last stage.
-template <int E, int OFF, int K, int S0, int LOGN = 0, bool LAZY = false>
+// UNI: the twiddle index is wave-uniform (scalar loads through the constant address space)
+template <int E, int OFF, int K, int S0, int LOGN = 0, bool LAZY = false, bool UNI = false>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
 #pragma unroll
@@ -23,7 +29,7 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
         const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
-            const double W = w[base + j], Wp = wp[base + j];
+            const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j], Wp = UNI ? ((ctw_t)wp)[base + j] : wp[base + j];
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
@@ -36,7 +42,7 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 
 using hxf::InvScale;
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, bool LAZY = false>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, bool LAZY = false, bool UNI = false>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -47,7 +53,7 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
 #pragma unroll
         for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
             double W = 0, Wp = 0;
-            if (!fused) { W = iw[base + j]; Wp = iwp[base + j]; }
+            if (!fused) { W = UNI ? ((ctw_t)iw)[base + j] : iw[base + j]; Wp = UNI ? ((ctw_t)iwp)[base + j] : iwp[base + j]; }
 #pragma unroll
             for (int c = 0; c < (1 << u); ++c) {
                 const int a0 = OFF + (j << (u + 1)) + c;
@@ -91,7 +97,7 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6)>(v, Gp, w, wp, m);
             constexpr bool PRIV = G::template wave_private<LO>;
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PASS + 1 < G::P - 1) {
@@ -171,7 +177,7 @@ struct WgNttF64 {
                                         [](int r, int t) { return G::template idxF<LO>(r, t); });
             }
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY>(v, Gp, iw, iwp, m, sc);
+            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6)>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc);
         }
     }
