@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
         // recomputes it; same value for in-range data). The registers already hold t_d in B order.
         double* ud = a.u + ((size_t(b) * (L + 1) + d) * L + d) * G::N;
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) (ud + r * G::T)[u32(tid)] = c[r];
+        for (int r = 0; r < G::E; ++r) __builtin_nontemporal_store(c[r], &(ud + r * G::T)[u32(tid)]);   // streamed to k_ksf_mac
         W::template inverse<true>(c, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) c[r] = hxf::lift(c[r], md.m);                    // canonical c_d, A order
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
         W::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m);
         double* dst = a.u + ((size_t(b) * (L + 1) + slot) * L + d) * G::N;
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) (dst + r * G::T)[u32(tid)] = v[r];
+        for (int r = 0; r < G::E; ++r) __builtin_nontemporal_store(v[r], &(dst + r * G::T)[u32(tid)]);
     }
 }
 
@@ -114,15 +114,15 @@ __global__ __launch_bounds__(256) void k_ksf_mac(KsArgsF a, u32 n) {
 #pragma unroll
         for (int d = 0; d < MAXL; ++d)
             if (d < (int)L) {
-                const d2 u = *reinterpret_cast<const d2*>(ub + size_t(d) * n);
+                const d2 u = __builtin_nontemporal_load(reinterpret_cast<const d2*>(ub + size_t(d) * n));   // read exactly once
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     acc0[e] = hxf::reduce(acc0[e] + hxf::mul_mod(u[e], key[d][0][e], m), m);
                     acc1[e] = hxf::reduce(acc1[e] + hxf::mul_mod(u[e], key[d][1][e], m), m);
                 }
             }
-        *reinterpret_cast<d2*>(a.prod + ((size_t(b) * 2 + 0) * (L + 1) + slot) * n + j) = acc0;
-        *reinterpret_cast<d2*>(a.prod + ((size_t(b) * 2 + 1) * (L + 1) + slot) * n + j) = acc1;
+        __builtin_nontemporal_store(acc0, reinterpret_cast<d2*>(a.prod + ((size_t(b) * 2 + 0) * (L + 1) + slot) * n + j));
+        __builtin_nontemporal_store(acc1, reinterpret_cast<d2*>(a.prod + ((size_t(b) * 2 + 1) * (L + 1) + slot) * n + j));
     }
 }
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
     const double* src = a.prod + (size_t(item) * (L + 1) + L) * G::N;
     double v[G::E];
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) v[r] = src[r * G::T + tid];
+    for (int r = 0; r < G::E; ++r) v[r] = __builtin_nontemporal_load(&src[r * G::T + tid]);
     WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
     double* dst = a.s + size_t(item) * G::N;
 #pragma unroll
