@@ -31,6 +31,69 @@ __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswit
     return xcd * q + (xcd < r ? xcd : r) + j;
 }
 
+// ---- small batches: one transform per workgroup, so that even a single keyswitch spreads over L*L + ... CUs ----
+// step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles
+template <int LOGN, int LOGE, bool LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 item = blockIdx.x;                                  // b*L + d
+    const u32 d = __builtin_amdgcn_readfirstlane(item % a.L);
+    const KsModF64 md = a.mods[d];
+    const double* tb = a.tables + size_t(d) * 4 * G::N;
+    const u64* src = a.t_target + size_t(item) * G::N;
+    double v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), md.m);
+    // step 2 for slot == d needs no transform: NTT_{q_d}(INTT_{q_d}(t_d) mod q_d) = t_d (the reference recomputes
+    // it; same value for in-range data). The registers already hold t_d in B order.
+    {
+        const u32 b = item / a.L;
+        double* ud = a.u + ((size_t(b) * (a.L + 1) + d) * a.L + d) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) ud[r * G::T + tid] = v[r];
+    }
+    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    double* dst = a.c + size_t(item) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = hxf::lift(v[r], md.m);
+}
+
+// step 2: u[b][slot][d] = NTT_{q_i}(c_d mod q_i) for slot != d (slot == d is written by k_ksf_intt), one
+// transform per workgroup, kept in the forward transform's register order ("B order", fully coalesced).
+// (Capping this kernel at 96 VGPRs so that a k_ksf_mac workgroup of the other lane could be co-resident was
+// measured: +12 % instructions, no throughput gain -- not done.)
+template <int LOGN, int LOGE, bool LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    // (b*L + d)*L + s, XCD-contiguous: the L transforms that read the same c_d run back to back on one XCD, so c_d
+    // comes from HBM once and from that XCD's L2 afterwards
+    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_f(blockIdx.x, gridDim.x));
+    const u32 bd = item / L, sidx = item - bd * L;
+    const u32 b = bd / L, d = bd - b * L;
+    const u32 slot = sidx + (sidx >= d ? 1u : 0u);                // 0..L without d; slot L is the special prime
+    const u32 i = slot < L ? slot : a.K - 1;
+    const KsModF64 md = a.mods[i];
+    const Mod m = md.m;
+    double* dst = a.u + ((size_t(b) * (L + 1) + slot) * L + d) * G::N;
+    double v[G::E];
+    const double* cd = a.c + (size_t(b) * L + d) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(cd[G::idxA(r, tid)], m);          // c_d mod q_i (intt1_redu.hpp:36-42)
+    const double* tb = a.tables + size_t(i) * 4 * G::N;
+    // no final range reduction (LAZY): |u| <= 1.91p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
+    // |result| < p); tests/cpp/f64_selftest.cpp replays exactly this chain against 128-bit integers
+    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = v[r];
+}
+
+// ---- large batches: one workgroup per polynomial of the INPUT, all its transforms back to back ----
 // steps 1-2 in one kernel: c_d = INTT_{q_d}(t_target[d]) (canonical), then u[b][slot][d] = NTT_{q_i}(c_d mod q_i)
 // for every slot. One workgroup per (b, d) keeps c_d in registers (A order is both the inverse transform's output
 // and the forward transform's input order) and runs the L forward transforms back to back: c never travels to
@@ -196,6 +259,8 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     static bool attr_set = false;
     if (!attr_set) {
         int rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_BYTES);
+        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_BYTES);
         if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_BYTES);
         if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE, LAZY>, G::LDS_BYTES);
         if (rc) return rc;
@@ -203,10 +268,24 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     }
     hipStream_t st = p->cur;
     const u32 L = a.L, nb = a.nb;
-    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    // one workgroup per input polynomial (all its transforms back to back) once that alone fills the chip twice;
+    // below that one workgroup per transform, so that small batches still spread over the CUs
+    const u32 cus = (u32)p->ctx->num_cu;
+    // (the same fusion of steps 4-7 -- s' in registers, L mod-down transforms per workgroup -- measured 8 % slower
+    // than the two kernels below: its epilogue loads cannot be requested early, tools/experiments/fused_down.patch)
+    static int fuse = -1;
+    if (fuse < 0) { const char* e = getenv("HEXL_KS_FUSE"); fuse = e ? atoi(e) : 1; }
+    const bool fused_up = (fuse & 1) && nb * L >= 2 * cus;
     // timing stages: 1 = steps 1-2 (inverse + mod-up transforms), 2 = steps 3-4, 4 = steps 5-7
-    if (stage_mask & 1)
-        hipLaunchKernelGGL((k_ksf_up<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1) {
+        if (fused_up) {
+            hipLaunchKernelGGL((k_ksf_up<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
+        } else {
+            hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
+            hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * L * L), dim3(G::T), G::LDS_BYTES, st, a);
+        }
+    }
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2) {
         const u32 threads = (L + 1) * (G::N / 2);
