@@ -232,17 +232,25 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(sk[G::idxA(r, tid)] + md.fix, m);   // intt2_redu.hpp:49-51
-    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);      // |w| <= 1.91p: |prod - w| <= 2.41p below
-
     const double* pk = a.prod + ((size_t(b) * 2 + k) * (L + 1) + i) * G::N;
     u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;
+    // prod is requested right after the cross-wave re-deal and lands during the remaining passes; result is
+    // requested first thing in the epilogue and lands during the (prod - w) * msf multiplications
+    double pv[G::E];
+    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {        // |w| <= 1.91p: |prod - w| <= 2.41p below
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
+    });
+    const u32 tB = u32(G::idxB(0, tid));
+    u64 old[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) old[r] = (res + G::idxB(r, 0))[tB];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(pv[r] - v[r], md.msf, md.msf_p, m);    // ms.hpp:70-82
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
-        const int idx = G::idxB(r, tid);
-        const double in = pk[r * G::T + tid] - v[r];                                   // ms.hpp:70-78
-        const double out = hxf::mul_shoup(in, md.msf, md.msf_p, m);                    // ms.hpp:80-82
-        const double rr = hxf::reduce(hxf::to_f64(res[idx]) + out, m);                 // fpga.cpp:453-457
-        res[idx] = hxf::from_f64(hxf::lift(rr, m));
+        const double rr = hxf::reduce(hxf::to_f64(old[r]) + v[r], m);                            // fpga.cpp:453-457
+        (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
     }
 }
 

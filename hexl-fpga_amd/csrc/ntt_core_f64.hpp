@@ -90,9 +90,12 @@ struct WgNttF64 {
     // FINAL = false (LAZY only): the range reduction after the last stage is left to the consumer, outputs are
     // then bounded by 1.91p instead of p/2 (two unreduced stages after the reduction at the last multiple of three;
     // f64_arith.hpp) -- mul_mod and mul_shoup of the mod-up / mod-down epilogues accept that.
-    template <int PASS, bool FRESH = false, bool FINAL = true>
+    // `after_cross` runs right after the first (cross-wave) re-deal: the place to request data the epilogue will
+    // need (the barriers and fences of the re-deals pin every load the compiler sees behind them).
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
+    template <int PASS, bool FRESH = false, bool FINAL = true, class Hook = NoHook>
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
-                                                    const double* wp, const Mod m) {
+                                                    const double* wp, const Mod m, Hook after_cross = Hook()) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
@@ -108,6 +111,7 @@ struct WgNttF64 {
                 redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
                                         [](int r, int t) { return G::idxB(r, t); });
             }
+            if constexpr (PASS == 0) after_cross();
             fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m);
         } else {
             fwd_last<0, FINAL>(v, tid, w, wp, m);
@@ -123,11 +127,11 @@ struct WgNttF64 {
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }
-    template <bool FRESH = false, bool FINAL = true>
+    template <bool FRESH = false, bool FINAL = true, class Hook = NoHook>
     __device__ static __forceinline__ void forward(double (&v)[E], double* lds, int tid, const double* w,
-                                                   const double* wp, const Mod m) {
+                                                   const double* wp, const Mod m, Hook after_cross = Hook()) {
         static_assert(G::P > 1, "single-pass geometries are not used");
-        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m);
+        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m, after_cross);
     }
     // every pass except the last (partial) one, ending with the re-deal into B layout; fwd_last<0> finishes.
     // Lets a persistent kernel slot the next polynomial's loads between the two.
