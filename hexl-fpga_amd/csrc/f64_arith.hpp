@@ -57,7 +57,7 @@ HX_HD double mul_shoup(double x, double w, double wp, const Mod m) {
     return __builtin_fma(-k, m.p, h) + l;
 }
 
-// a*b mod p for two variables, |a|,|b| <= p/2 + 2: |result| <= 0.7p.
+// a*b mod p for two variables, |a|,|b| <= p/2 + 2: |result| <= 0.7p (general bound in the LAZY notes below).
 HX_HD double mul_mod(double a, double b, const Mod m) {
     const double h = a * b;
     const double l = __builtin_fma(a, b, -h);
@@ -75,9 +75,12 @@ HX_HD uint64_t from_f64(double x) {
 }
 
 // ---- butterflies (both outputs centred) ---------------------------------------------------------
-// Cooley-Tukey / forward (device/keyswitch/ntt_core.hpp:285-291):  X' = X + W*Y, Y' = X - W*Y
-HX_HD void ct_bfly(double& X, double& Y, double w, double wp, const Mod m) {
-    const double t = mul_shoup(Y, w, wp, m);                 // |t| <= 0.75p
+// Cooley-Tukey / forward (device/keyswitch/ntt_core.hpp:285-291):  X' = X + W*Y, Y' = X - W*Y.
+// The forward butterflies take the quotient from the product itself (mul_mod) instead of a second table of
+// w/p: same six instructions, half the twiddle traffic and registers. (The inverse keeps the Shoup form: its
+// bound chain below needs the smaller error term.)
+HX_HD void ct_bfly(double& X, double& Y, double w, const Mod m) {
+    const double t = mul_mod(Y, w, m);                       // |t| <= 0.7p
     const double a = X + t, b = X - t;                       // |.| <= 1.25p + 2
     X = reduce(a, m);
     Y = reduce(b, m);
@@ -93,17 +96,21 @@ HX_HD void gs_bfly(double& X, double& Y, double w, double wp, const Mod m) {
 // Every value only has to stay an exactly representable integer, |x| < 2^53 ~ 3.97p here, which leaves room
 // to skip most range reductions:
 //   mul_shoup bound in this regime: |x*w mod p| <= (0.5 + 0.252*|x|/p) * p   (two roundings of |x*w/p| <= |x|/2)
-//   forward:  butterflies without reduce grow the bound c (|x| <= c*p) as c -> 1.252c + 0.5:
-//             0.5 -> 1.126 -> 1.910 -> 2.891 (< 3.97); a reduce of every element after each third stage
+//   mul_mod bound (|w| <= p/2):     |x*w mod p| <= (0.5 + 0.378*|x|/p) * p   (the quotient is taken from h = fl(x*w),
+//             so the split-off low part |l| <= ulp(h)/2 <= 0.126*|x| adds to the remainder); exact because
+//             |h - k*p| <= (0.5 + 0.252*|x|/p) * p < 2^53
+//   forward:  butterflies (mul_mod) without reduce grow the bound c (|x| <= c*p) as c -> 1.378c + 0.5:
+//             0.5 -> 1.189 -> 2.139 -> 3.447 (< 3.97); a reduce of every element after each third stage
 //             (and after the last) restarts the chain. 8 FP64 ops per butterfly + 6 every third stage.
+//             Without the reduce after the last stage the outputs are bounded by 2.14p.
 //   inverse:  sums double, so the sum output is reduced every stage (-> 0.5p) and the product output never:
 //             inputs <= p  =>  |X+Y|,|X-Y| <= 2p  =>  product <= (0.5 + 0.504)p ~ p: stable at c = 1. 11 ops.
 //   exactness of mul_shoup: |h - k*p| <= |result| + |l| <= 1.01p + 2^49 < 2^53.
 // tests/cpp/f64_selftest.cpp replays both schedules against exact integers and records the largest |x| seen.
 constexpr double LAZY_MAX_MODULUS = 2251799813685248.0 * (1.0 + 1.0 / 128.0);   // 2^51 * (1 + 2^-7)
 
-HX_HD void ct_bfly_lazy(double& X, double& Y, double w, double wp, const Mod m) {
-    const double t = mul_shoup(Y, w, wp, m);
+HX_HD void ct_bfly_lazy(double& X, double& Y, double w, const Mod m) {
+    const double t = mul_mod(Y, w, m);
     const double a = X + t, b = X - t;
     X = a;
     Y = b;

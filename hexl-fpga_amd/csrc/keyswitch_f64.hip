@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(cd[G::idxA(r, tid)], m);          // c_d mod q_i (intt1_redu.hpp:36-42)
     const double* tb = a.tables + size_t(i) * 4 * G::N;
-    // no final range reduction (LAZY): |u| <= 1.91p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
+    // no final range reduction (LAZY): |u| <= 2.14p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
     // |result| < p); tests/cpp/f64_selftest.cpp replays exactly this chain against 128-bit integers
     W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(c[r], m);                     // c_d mod q_i (intt1_redu.hpp:36-42)
         // not FRESH: other waves may still be reading their LDS block of the previous transform. No final range
-        // reduction (LAZY): |u| <= 1.91p, which mul_mod in k_ksf_mac accepts (tests/cpp/f64_selftest.cpp)
+        // reduction (LAZY): |u| <= 2.14p, which mul_mod in k_ksf_mac accepts (tests/cpp/f64_selftest.cpp)
         W::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m);
         double* dst = a.u + ((size_t(b) * (L + 1) + slot) * L + d) * G::N;
 #pragma unroll
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     // prod is requested right after the cross-wave re-deal and lands during the remaining passes; result is
     // requested first thing in the epilogue and lands during the (prod - w) * msf multiplications
     double pv[G::E];
-    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {        // |w| <= 1.91p: |prod - w| <= 2.41p below
+    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {        // |w| <= 2.14p: |prod - w| <= 2.64p below
 #pragma unroll
         for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
     });

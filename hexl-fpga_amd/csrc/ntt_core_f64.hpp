@@ -29,12 +29,12 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
         const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
-            const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j], Wp = UNI ? ((ctw_t)wp)[base + j] : wp[base + j];
+            const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
-                if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m);
-                else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m);
+                if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
+                else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
             }
         }
     }
@@ -88,7 +88,7 @@ struct WgNttF64 {
 
     // forward: A layout in, B layout out, all values centred. FRESH as in ntt_core.hpp (single-transform kernels).
     // FINAL = false (LAZY only): the range reduction after the last stage is left to the consumer, outputs are
-    // then bounded by 1.91p instead of p/2 (two unreduced stages after the reduction at the last multiple of three;
+    // then bounded by 2.14p instead of p/2 (two unreduced stages after the reduction at the last multiple of three;
     // f64_arith.hpp) -- mul_mod and mul_shoup of the mod-up / mod-down epilogues accept that.
     // `after_cross` runs right after the first (cross-wave) re-deal: the place to request data the epilogue will
     // need (the barriers and fences of the re-deals pin every load the compiler sees behind them).

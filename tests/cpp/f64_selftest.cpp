@@ -74,8 +74,8 @@ static void test_transforms(uint64_t n, uint64_t p) {
     for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
     for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1)
         for (uint64_t i = 0; i < mm; ++i) {
-            const double w = centre(roots[mm + i]), wp = w / (double)p;
-            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) hxf::ct_bfly(v[j], v[j + t], w, wp, m);
+            const double w = centre(roots[mm + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) hxf::ct_bfly(v[j], v[j + t], w, m);
         }
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "fwd n=%lu p=%lu i=%lu", n, p, i);
     // inverse (table from index 0, then * n^-1)
@@ -118,9 +118,9 @@ static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
     for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
         const bool red = hxf::lazy_fwd_reduce_after(s, logn);
         for (uint64_t i = 0; i < mm; ++i) {
-            const double w = centre(roots[mm + i]), wp = w / (double)p;
+            const double w = centre(roots[mm + i]);
             for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
-                if (red) hxf::ct_bfly(v[j], v[j + t], w, wp, m); else hxf::ct_bfly_lazy(v[j], v[j + t], w, wp, m);
+                if (red) hxf::ct_bfly(v[j], v[j + t], w, m); else hxf::ct_bfly_lazy(v[j], v[j + t], w, m);
                 track(v[j]); track(v[j + t]);
             }
         }
@@ -134,9 +134,9 @@ static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
         for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s2) {
             const bool red = hxf::lazy_fwd_reduce_after(s2, 0);
             for (uint64_t i = 0; i < mm; ++i) {
-                const double w = centre(roots[mm + i]), wp = w / (double)p;
+                const double w = centre(roots[mm + i]);
                 for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
-                    if (red) hxf::ct_bfly(u[j], u[j + t], w, wp, m); else hxf::ct_bfly_lazy(u[j], u[j + t], w, wp, m);
+                    if (red) hxf::ct_bfly(u[j], u[j + t], w, m); else hxf::ct_bfly_lazy(u[j], u[j + t], w, m);
                     track(u[j]); track(u[j + t]);
                 }
             }

@@ -15,8 +15,8 @@ __global__ __launch_bounds__(1024) void k(double* out, double seed, Mod m) {
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (VARIANT == 0) hxf::ct_bfly_lazy(v[i], v[i + 8], w[i], wp[i], m);
-            if (VARIANT == 1) hxf::ct_bfly(v[i], v[i + 8], w[i], wp[i], m);
+            if (VARIANT == 0) hxf::ct_bfly_lazy(v[i], v[i + 8], w[i], m);
+            if (VARIANT == 1) hxf::ct_bfly(v[i], v[i + 8], w[i], m);
             if (VARIANT == 2) { v[i] = hxf::reduce(v[i], m); v[i + 8] = hxf::reduce(v[i + 8], m); }
         }
 #pragma unroll
