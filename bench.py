@@ -192,10 +192,11 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "alg_bytes_per_launch": alg * a.batch,
-                           "kernel": "keyswitch pipeline (ks_intt + ks_modup + ks_moddown)",
+                           "kernel": "keyswitch pipeline (k_ksf_up + k_ksf_mac + k_ksf_intt_sp + k_ksf_moddown)",
                            "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps}
-        extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "ks_intt": stage[1],
-                                                             "ks_modup": stage[2], "ks_moddown": stage[3]},
+        extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "steps_1_2_inverse_and_modup": stage[1],
+                                                             "steps_3_4_mac_and_special_inverse": stage[2],
+                                                             "steps_5_7_moddown": stage[3]},
                  "device": ctx.describe()}
         if not a.no_extra:
             extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)

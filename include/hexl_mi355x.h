@@ -107,9 +107,10 @@ int hexl_dyadic_multiply_host(hexl_ctx* ctx, uint64_t* const* h_out, const uint6
 int hexl_keyswitch_host(hexl_ks_plan* plan, uint64_t* const* h_results,
                         const uint64_t* const* h_t_targets, size_t batch);
 
-/* timing hook for bench.py: average milliseconds per keyswitch launch and per stage kernel
- * (ks_intt / ks_modup / ks_moddown) over `iters` launches of a batch that fits one scratch chunk,
- * measured with hipEvents on the context's stream. */
+/* timing hook for bench.py: average milliseconds per keyswitch launch and per stage (s1: steps 1-2, inverse
+ * transforms + mod-up transforms; s2: steps 3-4, multiply-accumulate + special-prime inverse; s3: steps 5-7,
+ * mod-down) over `iters` launches of a batch that fits one scratch chunk, measured with hipEvents on the
+ * context's stream. */
 int hexl_ks_time_stages(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_target,
                         size_t batch, int iters, float* ms_out /* [4]: total, s1, s2, s3 */);
 
