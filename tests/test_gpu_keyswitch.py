@@ -96,3 +96,35 @@ def test_batch_chunks_and_accumulate(hx, ctx, dev, orc):
     ctx.sync()
     assert np.array_equal(hx.to_u64(d_r2).astype(object), (r0.astype(object) + 2 * e0.astype(object)) % qs)
     plan.close()
+
+
+@pytest.mark.parametrize("n,L,K,nb,strict", [(16384, 7, 8, 80, False), (16384, 7, 8, 80, True), (4096, 3, 4, 176, False)])
+def test_fused_and_per_transform_modup_agree(hx, ctx, dev, orc, monkeypatch, n, L, K, nb, strict):
+    """large batches run steps 1-2 as one workgroup per input polynomial (k_ksf_up: c stays in registers, L forward
+    transforms back to back), small ones as one workgroup per transform; both must give the oracle's bits"""
+    if strict:
+        monkeypatch.setenv("HEXL_KS_NOLAZY", "1")
+    case = KsCase(orc, n, L, K, seed=3 * n + L)
+    distinct = [case.inputs(orc, b) for b in range(3)]
+    ts = np.concatenate([distinct[b % 3][0] for b in range(nb)])
+    rs = np.concatenate([distinct[b % 3][1] for b in range(nb)])
+    want = [case.expected(orc, t, r) for t, r in distinct]
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("HEXL_KS_ONE_LANE", "1")             # one chunk of nb: nb * L >= 2 * CUs selects the fused kernel
+        plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+        plan.set_keys(case.keys)
+        d_t, d_r = hx.as_i64(ts).to(dev), hx.as_i64(rs).to(dev)
+        if fuse == "0":
+            # the per-transform kernels are what a batch below the threshold gets: run the same data in slices of 8
+            for b0 in range(0, nb, 8):
+                w = min(8, nb - b0)
+                plan.keyswitch(d_r[b0 * 2 * L * n:], d_t[b0 * L * n:], w)
+        else:
+            plan.keyswitch(d_r, d_t, nb)
+        ctx.sync()
+        outs.append(hx.to_u64(d_r).reshape(nb, -1))
+        plan.close()
+    for b in range(nb):
+        assert np.array_equal(outs[0][b], want[b % 3]), f"fused, instance {b}"
+    assert np.array_equal(outs[0], outs[1])
