@@ -217,7 +217,10 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     // chunks alternate between two lanes; a batch that fits one chunk is still split in two when it is large
     // enough to fill the chip twice, so the lanes always have something to overlap. Timing runs (ev) stay on one lane.
     size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
-    const bool two_lanes = !ev && batch >= 64 && !(getenv("HEXL_KS_ONE_LANE") && atoi(getenv("HEXL_KS_ONE_LANE")) == 1);
+    // (FP64 path: with one barrier per transform and steps 1-2 fused the lanes measure the same as one stream, so a
+    // batch that fits one chunk stays whole -- halves would fall below the fused kernel's threshold)
+    const bool two_lanes = !ev && batch >= 64 && !(getenv("HEXL_KS_ONE_LANE") && atoi(getenv("HEXL_KS_ONE_LANE")) == 1) &&
+                           !(p->use_f64 && batch <= chunk);
     if (two_lanes && batch <= chunk) chunk = (batch + 1) / 2;
     const size_t lane_words = chunk * scratch_words(p) * p->n;
     if (p->cap < chunk) {
@@ -242,7 +245,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     // the other's FP64-bound ones instead of both running the same kernel side by side
     size_t ci = 0, nb = 0;
     for (size_t b0 = 0; b0 < batch; b0 += nb, ++ci) {
-        const size_t want = (lanes == 2 && ci == 1) ? (chunk + 1) / 2 : chunk;
+        const size_t want = (lanes == 2 && ci == 1 && !p->use_f64) ? (chunk + 1) / 2 : chunk;
         nb = (batch - b0 < want) ? batch - b0 : want;
         const int lane = (int)(ci % lanes);
         p->cur = p->aux[lane];
