@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_modup(KsArgs a) {
         u64 v[G::E];
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = barrett64(cd[G::idxA(r, tid)], q, md.qbarr);   // intt1_redu.hpp:36-42
-        const u64* roots = opaque(tb);                  // keep twiddle loads inside the d loop
+        const u64* roots = tb + opaque_zero();          // keep twiddle loads inside the d loop
         W::forward_lazy(v, lds, tid, roots, roots + G::N, q);
         W::final_reduce(v, q);
         const u64* k0 = a.keys + ((size_t(d) * (L + 1) + slot) * 2) * G::N;
@@ -117,12 +117,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_modup(KsArgs a) {
         for (int r = 0; r < G::E; ++r) { p0[r * G::T + tid] = acc0[r]; p1[r * G::T + tid] = acc1[r]; }
     } else {
         // special-prime limb: INTT, then + floor(q_sp/2) mod q_sp (intt2_redu.hpp:25,43)
-        const u64* it = opaque(tb) + 2 * G::N;
+        const u64* it = tb + opaque_zero() + 2 * G::N;
         W::inverse(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
         u64* s0 = a.s + (size_t(b) * 2 + 0) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) s0[G::idxA(r, tid)] = csub(acc0[r] + md.half, q);
-        it = opaque(tb) + 2 * G::N;
+        it = tb + opaque_zero() + 2 * G::N;
         W::inverse(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
         u64* s1 = a.s + (size_t(b) * 2 + 1) * G::N;
 #pragma unroll

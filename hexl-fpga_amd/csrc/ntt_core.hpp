@@ -20,7 +20,7 @@
 
 // Optional scheduling fences inside the unrolled butterfly networks (every HX_FENCE_EVERY twiddles).
 #ifndef HX_FENCE_EVERY
-#define HX_FENCE_EVERY 0   /* 0 = no fences (measured: not needed once LICM is blocked, see opaque()) */
+#define HX_FENCE_EVERY 0   /* 0 = no fences (measured: not needed once LICM is blocked, see opaque_zero()) */
 #endif
 #if HX_FENCE_EVERY > 0
 #define HX_SCHED_FENCE(j) do { if ((((j) + 1) % HX_FENCE_EVERY) == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -64,11 +64,12 @@ __device__ __forceinline__ u64 csub_n(u64 x, u64 m, u64 negm) {
 
 // Twiddle loads do not depend on the loop a transform sits in (polynomial / decomposition index), so
 // LICM hoists ALL of them out of that loop and the register allocator spills hundreds of VGPRs
-// (measured: 0 -> 250 spills). Laundering the table pointer inside the loop body pins the loads.
-template <class T>
-__device__ __forceinline__ const T* opaque(const T* p) {
-    asm volatile("" : "+s"(p));
-    return p;
+// (measured: 0 -> 250 spills). An offset the compiler cannot see through, added inside the loop body, pins the
+// loads. (Laundering the POINTER instead loses its address space: every load through it becomes a FLAT load.)
+__device__ __forceinline__ u32 opaque_zero() {
+    u32 z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
 }
 
 template <int LOGN, int LOGE>

@@ -227,8 +227,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_persist(double* x, const
         for (int r = 0; r < G::E; ++r) v[r] = px[G::idxA(r, tid)];
     }
     for (int item = first; item < last; ++item) {
-        const double* tw = opaque(w);
-        const double* twp = opaque(wp);
+        const double* tw = w + opaque_zero();
+        const double* twp = wp + opaque_zero();
         // all passes but the last
         W::template fwd_pass_until_last<0>(v, ldsd, tid, tw, twp, m);
         if (item + 1 < last) {
