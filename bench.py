@@ -104,7 +104,7 @@ def cpu_baseline(orc_mod, case, budget_s=12.0):
         case.expected(orc_mod, t, r)
         done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 64:
+        if el > budget_s or done >= 1024:
             break
     return {"value": done / el, "unit": "keyswitches/s", "cores": 1, "kind": "port",
             "sample": f"{done} keyswitch(es) N={case.n} L={case.L} K={case.K}, oracle/hexl_oracle.c -O3, 1 thread of "
