@@ -201,23 +201,27 @@ def main():
         if not a.no_extra:
             extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
-            # the reference-representable shape 16384_6_7_7_2 (decomp 6, 7 key moduli)
-            case6 = KsCase(orc_mod, N, 6, 7, seed=99)
-            plan6 = hx.KeySwitchPlan(ctx, N, 6, 7, 7, 2, case6.moduli, case6.modswitch)
-            plan6.set_keys(case6.keys)
-            t6, r6 = device_inputs(hx, orc_mod, case6, a.batch, dev)
-            plan6.keyswitch(r6, t6, a.batch)
-            torch.cuda.synchronize()
-            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            f0.record()
-            for _ in range(3):
-                plan6.keyswitch(r6, t6, a.batch)
-            f1.record()
-            torch.cuda.synchronize()
-            ms6 = f0.elapsed_time(f1) / 3
-            extra["keyswitch_16384_6_7_7_2"] = {"keyswitches_per_s": a.batch / (ms6 * 1e-3),
-                                                "alg_GBps": ks_alg_bytes(N, 6) * a.batch / (ms6 * 1e-3) / 1e9}
-            plan6.close()
+            def other_shape(Lx, Kx, moduli=None):
+                cs = KsCase(orc_mod, N, Lx, Kx, seed=99, moduli=moduli)
+                pl = hx.KeySwitchPlan(ctx, N, Lx, Kx, Kx, 2, cs.moduli, cs.modswitch)
+                pl.set_keys(cs.keys)
+                tx, rx = device_inputs(hx, orc_mod, cs, a.batch, dev)
+                pl.keyswitch(rx, tx, a.batch)
+                torch.cuda.synchronize()
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record()
+                for _ in range(3):
+                    pl.keyswitch(rx, tx, a.batch)
+                f1.record()
+                torch.cuda.synchronize()
+                ms = f0.elapsed_time(f1) / 3
+                pl.close()
+                return {"keyswitches_per_s": a.batch / (ms * 1e-3),
+                        "alg_GBps": ks_alg_bytes(N, Lx) * a.batch / (ms * 1e-3) / 1e9}
+            # the reference-representable shape 16384_6_7_7_2 (decomp 6, 7 key moduli), 52-bit primes
+            extra["keyswitch_16384_6_7_7_2"] = other_shape(6, 7)
+            # the same shape with 48-bit primes (SEAL's default parameter sizes for N=16384): longer lazy-reduction period
+            extra["keyswitch_16384_6_7_7_2_48bit_primes"] = other_shape(6, 7, orc_mod.primes(7, 48, N))
         out["extra"] = extra
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(orc_mod, case)

@@ -193,8 +193,15 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
     bool f64_ok = !(getenv("HEXL_KS_INT") && atoi(getenv("HEXL_KS_INT")) == 1);
     for (u64 i = 0; i < K; ++i) f64_ok = f64_ok && h_moduli[i] < (1ULL << 52);
     p->use_f64 = f64_ok;
-    p->f64_lazy = f64_ok && !(getenv("HEXL_KS_NOLAZY") && atoi(getenv("HEXL_KS_NOLAZY")) == 1);
-    for (u64 i = 0; i < K; ++i) p->f64_lazy = p->f64_lazy && (double)h_moduli[i] <= hxf::LAZY_MAX_MODULUS;
+    p->f64_lazy = 0;
+    if (f64_ok && !(getenv("HEXL_KS_NOLAZY") && atoi(getenv("HEXL_KS_NOLAZY")) == 1)) {
+        double qmax = 0;
+        for (u64 i = 0; i < K; ++i) qmax = (double)h_moduli[i] > qmax ? (double)h_moduli[i] : qmax;
+        p->f64_lazy = hxf::lazy_period_for(qmax);
+        const char* e = getenv("HEXL_KS_PERIOD");               // testing: force a SHORTER period (always valid)
+        if (e && p->f64_lazy && atoi(e) > 0 && atoi(e) <= p->f64_lazy && (atoi(e) == 3 || atoi(e) == 6 || atoi(e) == 12))
+            p->f64_lazy = atoi(e);
+    }
     if (f64_ok) {
         std::vector<KsModF64> fm(K);
         std::vector<double> ft(size_t(K) * 4 * n);

@@ -120,7 +120,18 @@ HX_HD void gs_bfly_lazy(double& X, double& Y, double w, double wp, const Mod m) 
     X = reduce(s, m);
     Y = mul_shoup(d, w, wp, m);
 }
-// forward schedule: reduce every element after global stage s (1-based) when s % 3 == 0 or s is the last stage
-HX_HD constexpr bool lazy_fwd_reduce_after(int s, int logn) { return (s % 3 == 0) || (s == logn); }
+// forward schedule: reduce every element after global stage s (1-based) when s % period == 0 or s is the last stage
+HX_HD constexpr bool lazy_fwd_reduce_after(int s, int logn, int period = 3) { return (s % period == 0) || (s == logn); }
+
+// Smaller moduli leave more head room: with a = p * 2^-53 a forward butterfly grows the bound as
+// c -> (1 + 1.5a) c + 0.5 and every value must stay below c = 1/a (|x| < 2^53):
+//   p <= 2^51(1+2^-7): a = 0.252, limit 3.97: 0.5 -> 1.19 -> 2.14 -> 3.45                         period 3
+//   p <= 2^50:         a = 0.125, limit 8:    0.5 -> 1.09 -> 1.80 -> 2.64 -> 3.63 -> 4.81 -> 6.22  period 6
+//   p <= 2^49:         a = 0.0625, limit 16:  ... -> 11.8 after twelve stages                      period 12
+// (consumers of an un-reduced tail need c + 0.5 < 1/a: at most two tail stages follow a reduction for n <= 2^14.)
+// The inverse schedule does not change with the tier. tests/cpp/f64_selftest.cpp replays every tier.
+HX_HD constexpr int lazy_period_for(double max_modulus) {
+    return max_modulus <= 562949953421312.0 ? 12 : max_modulus <= 1125899906842624.0 ? 6 : max_modulus <= LAZY_MAX_MODULUS ? 3 : 0;
+}
 
 }  // namespace hxf

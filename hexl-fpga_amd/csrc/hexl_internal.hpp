@@ -74,7 +74,7 @@ struct hexl_ks_plan {
     bool have_keys = false;
     // FP64 path (all moduli < 2^52): same tables / keys as centred doubles
     bool use_f64 = false;
-    bool f64_lazy = false;            // all moduli <= hxf::LAZY_MAX_MODULUS: lazy-reduction kernels
+    int f64_lazy = 0;                 // forward reduction period of the lazy kernels (3, 6, 12 by modulus size); 0 = strict
     KsModF64* d_mods_f64 = nullptr;   // [K]
     double* d_tables_f64 = nullptr;   // [K][4][n]
     double* d_keys_f64 = nullptr;     // [L][L+1][2][n]

@@ -33,7 +33,7 @@ __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswit
 
 // ---- small batches: one transform per workgroup, so that even a single keyswitch spreads over L*L + ... CUs ----
 // step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 // transform per workgroup, kept in the forward transform's register order ("B order", fully coalesced).
 // (Capping this kernel at 96 VGPRs so that a k_ksf_mac workgroup of the other lane could be co-resident was
 // measured: +12 % instructions, no throughput gain -- not done.)
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY>;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
 // ~5 us per transform on that wait (tools/load_probe.hip, tools/ntt_timeline.hip). The waves of the workgroup only
 // meet at each transform's cross-wave re-deal, so early waves start the next slot while late ones still store.
 // u is kept in the forward transform's register order ("B order", fully coalesced).
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY>;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_ksf_mac(KsArgsF a, u32 n) {
 }
 
 // step 4: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2)  (mod q_sp), canonical
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
 }
 
 // steps 5-7: w = NTT((s' + fix_i) mod q_i); result += (prod - w) * msf_i
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY>;
@@ -261,7 +261,7 @@ static int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
     static bool attr_set = false;
@@ -322,22 +322,26 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.s = a.prod + p->cap * 2 * (L + 1) * n;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
-    if (p->f64_lazy) {      // every modulus <= 2^51(1+2^-7): most range reductions are skipped (f64_arith.hpp)
+    // LAZY template argument = forward reduction period (f64_arith.hpp): 3 when every modulus <= 2^51(1+2^-7), 6 / 12
+    // for moduli <= 2^50 / 2^49 (N = 16384 only; the smaller transforms keep 3), 0 = strict
+    if (p->f64_lazy) {
         switch (p->logn) {
-            case 10: return run_chunk_f64<10, 4, true>(p, a, stage_mask, ev);
-            case 11: return run_chunk_f64<11, 5, true>(p, a, stage_mask, ev);
-            case 12: return run_chunk_f64<12, 5, true>(p, a, stage_mask, ev);
-            case 13: return run_chunk_f64<13, 5, true>(p, a, stage_mask, ev);
-            case 14: return run_chunk_f64<14, 4, true>(p, a, stage_mask, ev);
+            case 10: return run_chunk_f64<10, 4, 3>(p, a, stage_mask, ev);
+            case 11: return run_chunk_f64<11, 5, 3>(p, a, stage_mask, ev);
+            case 12: return run_chunk_f64<12, 5, 3>(p, a, stage_mask, ev);
+            case 13: return run_chunk_f64<13, 5, 3>(p, a, stage_mask, ev);
+            case 14: return p->f64_lazy == 12 ? run_chunk_f64<14, 4, 12>(p, a, stage_mask, ev)
+                          : p->f64_lazy == 6 ? run_chunk_f64<14, 4, 6>(p, a, stage_mask, ev)
+                                             : run_chunk_f64<14, 4, 3>(p, a, stage_mask, ev);
             default: return HEXL_E_BADARG;
         }
     }
     switch (p->logn) {
-        case 10: return run_chunk_f64<10, 4, false>(p, a, stage_mask, ev);
-        case 11: return run_chunk_f64<11, 5, false>(p, a, stage_mask, ev);
-        case 12: return run_chunk_f64<12, 5, false>(p, a, stage_mask, ev);
-        case 13: return run_chunk_f64<13, 5, false>(p, a, stage_mask, ev);
-        case 14: return run_chunk_f64<14, 4, false>(p, a, stage_mask, ev);
+        case 10: return run_chunk_f64<10, 4, 0>(p, a, stage_mask, ev);
+        case 11: return run_chunk_f64<11, 5, 0>(p, a, stage_mask, ev);
+        case 12: return run_chunk_f64<12, 5, 0>(p, a, stage_mask, ev);
+        case 13: return run_chunk_f64<13, 5, 0>(p, a, stage_mask, ev);
+        case 14: return run_chunk_f64<14, 4, 0>(p, a, stage_mask, ev);
         default: return HEXL_E_BADARG;
     }
 }

@@ -67,7 +67,7 @@ __device__ __attribute__((noinline)) void slow_inv(u64* px, u64* lds, const u64*
     for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
 }
 
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restrict__ x, const u64* __restrict__ roots,
                                                                   const u64* __restrict__ precon, u64 q,
                                                                   const double* __restrict__ w,
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     }
 }
 
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restrict__ x, const u64* __restrict__ iroots,
                                                                   const u64* __restrict__ iprecon, u64 q, u64 inv_n,
                                                                   u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p,
@@ -248,7 +248,7 @@ static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
     return (int)hipGetLastError();
 }
 
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q,
                         const double* w, const double* wp, const u32* viol) {
     using G = Geom<LOGN, LOGE>;
@@ -263,7 +263,7 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
     return (int)hipGetLastError();
 }
 
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const u64* ip, u64 q, u64 a, u64 ap, u64 b,
                         u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* viol) {
     using G = Geom<LOGN, LOGE>;
@@ -278,7 +278,7 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     return (int)hipGetLastError();
 }
 
-template <bool LAZY>
+template <int LAZY>
 static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, const double* w,
                           const double* wp, const u32* v) {
     switch (logn) {
@@ -290,7 +290,7 @@ static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64
         default: return HEXL_E_BADARG;
     }
 }
-template <bool LAZY>
+template <int LAZY>
 static int dispatch_inv_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, u64 a, u64 ap,
                           u64 b, u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* v) {
     switch (logn) {
@@ -316,8 +316,11 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
         double *w, *wp; u32* viol;
         int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol);
         if (rc) return rc;
-        return (double)q <= hxf::LAZY_MAX_MODULUS ? dispatch_fwd_x<true>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
-                                                  : dispatch_fwd_x<false>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+        const int period = hxf::lazy_period_for((double)q);       // fewer range reductions for smaller moduli (N = 16384)
+        if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, w, wp, viol);
+        if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, w, wp, viol);
+        return period ? dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
+                      : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
     }
     switch (logn) {
         case 10: return launch_fwd<10, 4>(ctx, x, batch, roots, precon, q);
@@ -343,8 +346,8 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
         auto centre = [&](u64 v) { return v > q / 2 ? (double)v - pd : (double)v; };
         hxf::InvScale sc;
         sc.n = centre(a); sc.n_p = sc.n / pd; sc.nw = centre(b); sc.nw_p = sc.nw / pd;
-        return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<true>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol)
-                                           : dispatch_inv_x<false>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol);
+        return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<3>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol)
+                                           : dispatch_inv_x<0>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol);
     }
     switch (logn) {
         case 10: return launch_inv<10, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp);

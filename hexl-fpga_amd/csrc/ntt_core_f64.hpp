@@ -17,16 +17,16 @@ using hxf::Mod;
 // loop (k_ksf_up) loses its scalar (s_load) twiddle fetches for the wave-uniform passes -- the stores might alias.
 typedef const __attribute__((address_space(4))) double* ctw_t;
 
-// LAZY (moduli <= hxf::LAZY_MAX_MODULUS): butterflies skip the range reduction except after every third
+// LAZY = forward reduction period (0: strict; 3, 6 or 12 by modulus size, f64_arith.hpp): butterflies skip the range reduction except after every LAZY-th
 // global stage and after the last one (bounds in f64_arith.hpp). LOGN is only needed to find the last stage.
 // UNI: the twiddle index is wave-uniform (scalar loads through the constant address space)
-template <int E, int OFF, int K, int S0, int LOGN = 0, bool LAZY = false, bool UNI = false>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN);
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
@@ -42,7 +42,7 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 
 using hxf::InvScale;
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, bool LAZY = false, bool UNI = false>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
     __syncthreads();
 }
 
-template <int LOGN, int LOGE, bool LAZY = false>
+template <int LOGN, int LOGE, int LAZY = 0>
 struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;

@@ -101,7 +101,7 @@ static void test_transforms(uint64_t n, uint64_t p) {
 static double g_max_abs = 0;
 static inline void track(double x) { double a = x < 0 ? -x : x; if (a > g_max_abs) g_max_abs = a; }
 
-static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
+static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial, int period = 3) {
     hxf::Mod m{(double)p, 1.0 / (double)p};
     int logn = 0; while ((1ull << logn) < n) ++logn;
     std::vector<uint64_t> blk(4 * n);
@@ -116,7 +116,7 @@ static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
     for (uint64_t i = 0; i < n; ++i) v[i] = centre(x[i]);
     int s = 1;
     for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
-        const bool red = hxf::lazy_fwd_reduce_after(s, logn);
+        const bool red = hxf::lazy_fwd_reduce_after(s, logn, period);
         for (uint64_t i = 0; i < mm; ++i) {
             const double w = centre(roots[mm + i]);
             for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
@@ -132,7 +132,7 @@ static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial) {
         for (uint64_t i = 0; i < n; ++i) u[i] = centre(x[i]);
         int s2 = 1;
         for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s2) {
-            const bool red = hxf::lazy_fwd_reduce_after(s2, 0);
+            const bool red = hxf::lazy_fwd_reduce_after(s2, 0, period);
             for (uint64_t i = 0; i < mm; ++i) {
                 const double w = centre(roots[mm + i]);
                 for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
@@ -212,6 +212,22 @@ int main() {
         }
         std::printf("lazy schedules: max |x| seen = 2^%.3f (limit 2^53)\n", log2(g_max_abs));
         CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded");
+        // longer reduction periods for smaller moduli (f64_arith.hpp: lazy_period_for): the largest admissible prime
+        // = 1 mod 2^15 of each tier and one well inside it, at the period the plan would choose
+        for (int tier = 0; tier < 2; ++tier) {
+            const uint64_t top = tier == 0 ? (1ull << 50) : (1ull << 49);
+            const int period = tier == 0 ? 6 : 12;
+            std::vector<uint64_t> tp;
+            for (uint64_t v = top - 32767; tp.empty(); v -= 32768) if (orc_is_prime(v)) tp.push_back(v);
+            orc_generate_primes(tmp, 2, tier == 0 ? 49 : 47, 16384); tp.push_back(tmp[0]);
+            g_max_abs = 0;
+            for (uint64_t p : tp) {
+                CHECK(hxf::lazy_period_for((double)p) >= period, "prime %lu: period %d not admissible", p, period);
+                for (uint64_t n : {1024ull, 16384ull}) { test_transforms_lazy(n, p, false, period); test_transforms_lazy(n, p, true, period); }
+            }
+            std::printf("period %2d (p <= 2^%d): max |x| seen = 2^%.3f (limit 2^53)\n", period, tier == 0 ? 50 : 49, log2(g_max_abs));
+            CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded for period %d", period);
+        }
     }
     std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());
     return failures ? 1 : 0;

@@ -33,7 +33,8 @@ def test_vs_oracle(hx, ctx, dev, orc, n, L, K):
 
 
 @pytest.mark.parametrize("which", ["f64_lazy_51bit", "f64_strict_just_below_2^52", "int_55bit", "int_forced_51bit",
-                                   "f64_strict_forced_51bit", "mixed_30_to_52bit"])
+                                   "f64_strict_forced_51bit", "mixed_30_to_52bit", "f64_period6_just_below_2^50",
+                                   "f64_period12_just_below_2^49", "f64_period3_forced_on_48bit"])
 def test_every_arithmetic_path(hx, ctx, dev, orc, monkeypatch, which):
     """the three kernel families must agree with the oracle: FP64 lazy (all moduli <= 2^51(1+2^-7)), FP64 strict
     (any modulus < 2^52) and the 64-bit integer kernels (moduli up to 2^60, also reachable with HEXL_KS_INT=1)"""
@@ -46,6 +47,13 @@ def test_every_arithmetic_path(hx, ctx, dev, orc, monkeypatch, which):
     elif which == "mixed_30_to_52bit":                      # like the SEAL bridge run: 52,30,30,40,... bit primes
         moduli = [primes_below(orc, 1, 1 << 52, n)[0], orc.primes(1, 30, n)[0], orc.primes(1, 40, n)[0],
                   orc.primes(2, 51, n)[1]]
+    elif which == "f64_period6_just_below_2^50":            # fewer range reductions for smaller moduli (f64_arith.hpp)
+        moduli = primes_below(orc, K, 1 << 50, n)
+    elif which == "f64_period12_just_below_2^49":
+        moduli = primes_below(orc, K, 1 << 49, n)
+    elif which == "f64_period3_forced_on_48bit":
+        moduli = orc.primes(K, 48, n)
+        monkeypatch.setenv("HEXL_KS_PERIOD", "3")
     if which == "int_forced_51bit":
         monkeypatch.setenv("HEXL_KS_INT", "1")
     if which == "f64_strict_forced_51bit":

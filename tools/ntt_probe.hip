@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_dual(double* x, const do
 // ---- half-size LDS exchange: the re-deal goes through LDS in two halves (index < N/2, then >= N/2), so a
 // workgroup needs 70 KiB instead of 140 KiB and TWO workgroups fit on a CU (512 threads x 32 coefficients each,
 // 128 VGPRs): one's stalls (loads, barriers, LDS) are covered by the other's FP64 work.
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 struct HalfX {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -170,7 +170,7 @@ struct HalfX {
     }
 };
 
-template <int LOGN, int LOGE, bool LAZY, int WPS, int STAGGER = 0>
+template <int LOGN, int LOGE, int LAZY, int WPS, int STAGGER = 0>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), WPS) void k_halfx(double* x, const double* w, const double* wp, Mod m) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), WPS) void k_halfx(double* x, co
     for (int r = 0; r < G::E; ++r) px[r * G::T + tid] = v[r];
 }
 
-template <int LOGN, int LOGE, bool LAZY, int WPS, int STAGGER = 0>
+template <int LOGN, int LOGE, int LAZY, int WPS, int STAGGER = 0>
 float run_halfx(double* d, const double* w, const double* wp, int batch, const char* name) {
     using G = Geom<LOGN, LOGE>;
     Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
@@ -211,7 +211,7 @@ float run_halfx(double* d, const double* w, const double* wp, int batch, const c
 // ---- persistent workgroups with register prefetch: one workgroup per CU walks a contiguous range of
 // polynomials; the next polynomial's coefficients are requested before the last (short) register pass of the
 // current one, so the HBM latency and the workgroup relaunch gap disappear from the critical path.
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_persist(double* x, const double* w, const double* wp, Mod m, int total) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY>;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_persist(double* x, const
     }
 }
 
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 float run_persist(double* d, const double* w, const double* wp, int batch, int grid) {
     using G = Geom<LOGN, LOGE>;
     Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
@@ -297,7 +297,7 @@ float run(double* d, const double* w, const double* wp, int batch, const char* n
 
 // two streams, each running the half-LDS kernel on half of the batch: workgroups of the two grids share CUs but
 // start at unrelated times, i.e. co-resident workgroups are NOT in lockstep. Compare with one stream.
-template <int LOGN, int LOGE, bool LAZY>
+template <int LOGN, int LOGE, int LAZY>
 void run_two_streams(double* d, const double* w, const double* wp, int batch) {
     using G = Geom<LOGN, LOGE>;
     Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
@@ -370,7 +370,7 @@ int main() {
         hipLaunchKernelGGL((k_probe<14, 4, 0>), dim3(8), dim3(1024), LB, 0, d, w, wp, m);
         hipMemcpy(r1.data(), d, r1.size() * 8, hipMemcpyDeviceToHost);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-        auto kp = k_persist<14, 4, false>;
+        auto kp = k_persist<14, 4, 0>;
         { const int lb = (int)LB; hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, lb); }
         hipLaunchKernelGGL(kp, dim3(3), dim3(1024), LB, 0, d, w, wp, m, 8);
         hipMemcpy(r2.data(), d, r2.size() * 8, hipMemcpyDeviceToHost);
@@ -378,12 +378,12 @@ int main() {
         printf("persist vs single mismatches: %zu\n", bad);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     }
-    run_persist<14, 4, false>(d, w, wp, batch, 256);
-    run_persist<14, 4, true>(d, w, wp, batch, 256);
-    run_persist<14, 4, true>(d, w, wp, batch, 512);
-    run_halfx<14, 4, true, 1>(d, w, wp, batch, "E=16 lazy half-exchange, 1 WG");
-    run_halfx<14, 4, true, 8>(d, w, wp, batch, "E=16 lazy half-exchange, 64 VGPR cap (2 WG/CU)");
-    run_halfx<14, 4, true, 8, 3>(d, w, wp, batch, "E=16 lazy half-exch, 64 VGPR, stagger 3");
+    run_persist<14, 4, 0>(d, w, wp, batch, 256);
+    run_persist<14, 4, 3>(d, w, wp, batch, 256);
+    run_persist<14, 4, 3>(d, w, wp, batch, 512);
+    run_halfx<14, 4, 3, 1>(d, w, wp, batch, "E=16 lazy half-exchange, 1 WG");
+    run_halfx<14, 4, 3, 8>(d, w, wp, batch, "E=16 lazy half-exchange, 64 VGPR cap (2 WG/CU)");
+    run_halfx<14, 4, 3, 8, 3>(d, w, wp, batch, "E=16 lazy half-exch, 64 VGPR, stagger 3");
     {   // correctness of the half-exchange kernel vs the single one (E=32 outputs are in the E=32 B order: compare sorted sums)
         std::vector<double> r1(size_t(4) * N), r2(size_t(4) * N);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
@@ -393,8 +393,8 @@ int main() {
         hipLaunchKernelGGL((k_probe<14, 5, 0>), dim3(4), dim3(512), LB5, 0, d, w, wp, m);
         hipMemcpy(r1.data(), d, r1.size() * 8, hipMemcpyDeviceToHost);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-        const int lbh = (int)(HalfX<14, 5, false>::HALF_WORDS * 8 + 64);
-        auto kh = k_halfx<14, 5, false, 4>;
+        const int lbh = (int)(HalfX<14, 5, 0>::HALF_WORDS * 8 + 64);
+        auto kh = k_halfx<14, 5, 0, 4>;
         hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, lbh);
         hipLaunchKernelGGL(kh, dim3(4), dim3(512), lbh, 0, d, w, wp, m);
         hipMemcpy(r2.data(), d, r2.size() * 8, hipMemcpyDeviceToHost);
@@ -402,16 +402,16 @@ int main() {
         printf("halfx vs single (E=32) mismatches: %zu\n", bad);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     }
-    run_halfx<14, 5, false, 4>(d, w, wp, batch, "strict, 128 VGPR cap");
-    run_halfx<14, 5, true, 4>(d, w, wp, batch, "lazy, 128 VGPR cap");
-    run_halfx<14, 5, true, 2>(d, w, wp, batch, "lazy, 256 VGPR (1 WG/CU)");
-    run_halfx<14, 5, false, 4, 1>(d, w, wp, batch, "strict, stagger 1");
-    run_halfx<14, 5, false, 4, 2>(d, w, wp, batch, "strict, stagger 2");
-    run_halfx<14, 5, false, 4, 3>(d, w, wp, batch, "strict, stagger 3");
-    run_halfx<14, 5, false, 4, 5>(d, w, wp, batch, "strict, stagger 5");
-    run_halfx<14, 5, true, 4, 3>(d, w, wp, batch, "lazy, stagger 3");
-    run_two_streams<14, 5, true>(d, w, wp, batch);
-    run_two_streams<14, 5, false>(d, w, wp, batch);
+    run_halfx<14, 5, 0, 4>(d, w, wp, batch, "strict, 128 VGPR cap");
+    run_halfx<14, 5, 3, 4>(d, w, wp, batch, "lazy, 128 VGPR cap");
+    run_halfx<14, 5, 3, 2>(d, w, wp, batch, "lazy, 256 VGPR (1 WG/CU)");
+    run_halfx<14, 5, 0, 4, 1>(d, w, wp, batch, "strict, stagger 1");
+    run_halfx<14, 5, 0, 4, 2>(d, w, wp, batch, "strict, stagger 2");
+    run_halfx<14, 5, 0, 4, 3>(d, w, wp, batch, "strict, stagger 3");
+    run_halfx<14, 5, 0, 4, 5>(d, w, wp, batch, "strict, stagger 5");
+    run_halfx<14, 5, 3, 4, 3>(d, w, wp, batch, "lazy, stagger 3");
+    run_two_streams<14, 5, 3>(d, w, wp, batch);
+    run_two_streams<14, 5, 0>(d, w, wp, batch);
     run<14, 5, 0>(d, w, wp, batch, "full");
     run<14, 5, 9>(d, w, wp, batch, "no global load/store");
     run<14, 5, 15>(d, w, wp, batch, "ALU only");

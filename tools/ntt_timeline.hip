@@ -17,7 +17,7 @@ __device__ __forceinline__ unsigned long long now() { return __builtin_readcycle
 #define PIN() _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) asm volatile("" : "+v"(v[r_]))
 #define STAMP(i, waits) do { PIN(); asm volatile(waits ::: "memory"); if ((tid & 63) == 0) st[i] = now(); PIN(); } while (0)
 
-template <bool LAZY, int STAGGER>
+template <int LAZY, int STAGGER>
 __global__ __launch_bounds__(1024) void k_timeline(double* x, const double* w, const double* wp, Mod m,
                                                    unsigned long long* stamps, unsigned* hwid) {
     using G = Geom<14, 4>;
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice); hipMemcpy(w, hwv.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(wp, hwp.data(), N * 8, hipMemcpyHostToDevice);
     Mod m{2251799814045697.0, 1.0 / 2251799814045697.0};
     for (int variant = 0; variant < 3; ++variant) {
-    auto kern = variant == 0 ? k_timeline<true, 0> : variant == 1 ? k_timeline<true, 45> : k_timeline<true, 90>;
+    auto kern = variant == 0 ? k_timeline<3, 0> : variant == 1 ? k_timeline<3, 45> : k_timeline<3, 90>;
     printf("---- first-round stagger: %s\n", variant == 0 ? "none" : variant == 1 ? "half a period" : "one period");
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
