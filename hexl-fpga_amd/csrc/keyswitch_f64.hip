@@ -1,11 +1,13 @@
 // keyswitch_f64.hip -- K4 on the FP64 pipe: the production keyswitch path when every modulus is < 2^52
-// (the reference's own limit, host/src/keyswitch.cpp:32). Same three fused kernels and dataflow as
-// keyswitch.hip; arithmetic from f64_arith.hpp (exact integers in doubles), so
-// results are bit-identical to the integer path and to the reference's canonical pipeline.
+// (the reference's own limit, host/src/keyswitch.cpp:32). Dataflow of SURVEY 2.1-K4 steps 1-7 as four kernels per
+// chunk of instances -- k_ksf_up (steps 1-2), k_ksf_mac (3), k_ksf_intt_sp (4), k_ksf_moddown (5-7); small batches
+// split steps 1-2 into k_ksf_intt + k_ksf_ntt_up. Arithmetic from f64_arith.hpp (exact integers in doubles), so
+// results are bit-identical to the integer path (keyswitch.hip) and to the reference's canonical pipeline.
 //
-// HBM-resident intermediates are doubles: c (canonical, natural order), prod (centred, natural order),
-// s' (canonical, natural order), keys and twiddles (centred; keys in the mod-up kernel's register order).
-// Only t_target (read) and result (read-modify-write) are converted from/to uint64.
+// HBM-resident intermediates are doubles: c (canonical, natural order; small batches only), u and prod in the
+// forward transform's register order ("B order": stored as [register][thread], fully coalesced, and consumed the
+// same way), s' (canonical, natural order); keys in B order too, twiddles centred. Only t_target (read) and result
+// (read-modify-write) are converted from/to uint64.
 #include <stdlib.h>
 
 #include "hexl_internal.hpp"
@@ -18,7 +20,7 @@ struct KsArgsF {
     const double* tables;    // [K][4][n]: w, w/p, inverse w (first entry at index 1), inverse w/p
     const double* keys;      // [L][L+1][2][n] centred, B order
     double* c;               // [chunk][L][n]          canonical, natural order
-    double* u;               // [chunk][L+1][L][n]     centred, B order
+    double* u;               // [chunk][L+1][L][n]     |u| <= 2.14p (no final range reduction), B order
     double* prod;            // [chunk][2][L+1][n]     centred, B order
     double* s;               // [chunk][2][n]          canonical, natural order
     const u64* t_target;     // [chunk][L][n]
