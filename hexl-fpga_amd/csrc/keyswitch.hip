@@ -238,8 +238,10 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     }
     hipStream_t user = p->ctx->stream;
     const int lanes = two_lanes ? 2 : 1;
-    HX_CHECK(hipEventRecord(p->ev_start, user));                      // lanes start after everything queued so far
-    for (int l = 0; l < lanes; ++l) HX_CHECK(hipStreamWaitEvent(p->aux[l], p->ev_start, 0));
+    if (lanes == 2) {                                                 // lanes start after everything queued so far
+        HX_CHECK(hipEventRecord(p->ev_start, user));
+        for (int l = 0; l < lanes; ++l) HX_CHECK(hipStreamWaitEvent(p->aux[l], p->ev_start, 0));
+    }
     const size_t n = p->n, L = p->L;
     // lane 1's first chunk is half-sized: the lanes then run out of phase, so one lane's HBM-bound kernels overlap
     // the other's FP64-bound ones instead of both running the same kernel side by side
@@ -248,7 +250,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         const size_t want = (lanes == 2 && ci == 1 && !p->use_f64) ? (chunk + 1) / 2 : chunk;
         nb = (batch - b0 < want) ? batch - b0 : want;
         const int lane = (int)(ci % lanes);
-        p->cur = p->aux[lane];
+        p->cur = lanes == 2 ? p->aux[lane] : user;                   // one lane: straight on the caller's stream
         p->cur_scratch = p->d_scratch + size_t(lane) * p->cap * scratch_words(p) * n;
         int rc;
         if (p->use_f64) {
@@ -274,7 +276,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         }
         if (rc) return rc;
     }
-    for (int l = 0; l < lanes; ++l) {                                  // the caller's stream continues after both lanes
+    for (int l = 0; lanes == 2 && l < lanes; ++l) {                    // the caller's stream continues after both lanes
         HX_CHECK(hipEventRecord(p->ev_done[l], p->aux[l]));
         HX_CHECK(hipStreamWaitEvent(user, p->ev_done[l], 0));
     }
