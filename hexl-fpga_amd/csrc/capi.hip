@@ -330,25 +330,90 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 #include <atomic>
 #include <functional>
 #include <thread>
+#include <future>
+#include <deque>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
 
 static unsigned host_threads() {
     static unsigned n = 0;
     if (!n) {
         const char* e = getenv("HEXL_HOST_THREADS");
-        n = e ? (unsigned)atoi(e) : std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        n = e ? (unsigned)atoi(e) : std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
         if (!n) n = 1;
     }
     return n;
 }
 
+// Persistent host workers for the staging copies (spawning threads per sub-batch cost more than the copies:
+// 64 threads measured slower than 8). Jobs are index ranges; several jobs may be in flight (the unpack of one
+// sub-batch runs beside the pack of the next), workers drain them front to back.
+namespace {
+struct HostJob {
+    std::function<void(size_t)> fn;
+    size_t count = 0;
+    std::atomic<size_t> next{0}, done{0};
+};
+class HostPool {
+  public:
+    static HostPool& get() { static HostPool p; return p; }
+    std::shared_ptr<HostJob> submit(size_t count, std::function<void(size_t)> fn) {
+        auto j = std::make_shared<HostJob>();
+        j->fn = std::move(fn); j->count = count;
+        if (!count) return j;
+        { std::lock_guard<std::mutex> g(m_); jobs_.push_back(j); }
+        cv_.notify_all();
+        return j;
+    }
+    void wait(const std::shared_ptr<HostJob>& j) {
+        if (!j) return;
+        work_on(j.get());                                         // the caller helps instead of sleeping
+        std::unique_lock<std::mutex> g(m_);
+        done_cv_.wait(g, [&] { return j->done.load() >= j->count; });
+    }
+  private:
+    HostPool() {
+        const unsigned n = host_threads();
+        for (unsigned t = 0; t + 1 < n; ++t) th_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void work_on(HostJob* j) {
+        for (size_t i; (i = j->next.fetch_add(1)) < j->count;) {
+            j->fn(i);
+            if (j->done.fetch_add(1) + 1 == j->count) { std::lock_guard<std::mutex> g(m_); done_cv_.notify_all(); }
+        }
+    }
+    void loop() {
+        for (;;) {
+            std::shared_ptr<HostJob> j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] {
+                    while (!jobs_.empty() && jobs_.front()->next.load() >= jobs_.front()->count) jobs_.pop_front();
+                    return stop_ || !jobs_.empty();
+                });
+                if (stop_) return;
+                j = jobs_.front();
+            }
+            work_on(j.get());
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::shared_ptr<HostJob>> jobs_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
+};
+}  // namespace
+
 static void parallel_for(size_t count, const std::function<void(size_t)>& fn) {
-    const unsigned nt = (unsigned)std::min<size_t>(host_threads(), count);
-    if (nt <= 1) { for (size_t i = 0; i < count; ++i) fn(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < count;) fn(i); });
-    for (auto& t : th) t.join();
+    if (count <= 1 || host_threads() <= 1) { for (size_t i = 0; i < count; ++i) fn(i); return; }
+    HostPool::get().wait(HostPool::get().submit(count, fn));
 }
 
 static int pipe_init(hexl_ctx* c) {
@@ -378,21 +443,27 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     if (rc) return rc;
     const size_t S = std::min(batch, sh.sub);
     const size_t in_slab = (sh.shared + S * sh.in1 + 255) & ~size_t(255);
-    const size_t out_slab = sh.in_place ? 0 : ((S * sh.out1 + 255) & ~size_t(255));
-    const size_t set = in_slab + out_slab;
-    rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, 2 * set);
-    if (!rc) rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, 2 * set);
+    // in-place primitives compute inside the device input slab, but on the HOST side every slab set has its own
+    // download area, so that unpacking sub-batch k can overlap packing sub-batch k+2 into the same set
+    const size_t out_slab = (S * (sh.in_place ? sh.in1 : sh.out1) + 255) & ~size_t(255);
+    const size_t hset = in_slab + out_slab, dset = in_slab + (sh.in_place ? 0 : out_slab);
+    rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, 2 * dset);
+    if (!rc) rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, 2 * hset);
     if (rc) return rc;
     const size_t nsub = (batch + S - 1) / S;
-    auto h_in = [&](size_t k) { return (char*)c->h_stage + (k & 1) * set; };
-    auto d_in = [&](size_t k) { return (char*)c->d_stage + (k & 1) * set; };
-    auto h_out = [&](size_t k) { return sh.in_place ? h_in(k) + sh.shared : h_in(k) + in_slab; };
+    auto h_in = [&](size_t k) { return (char*)c->h_stage + (k & 1) * hset; };
+    auto d_in = [&](size_t k) { return (char*)c->d_stage + (k & 1) * dset; };
+    auto h_out = [&](size_t k) { return h_in(k) + in_slab; };
     auto d_out = [&](size_t k) { return sh.in_place ? d_in(k) + sh.shared : d_in(k) + in_slab; };
+    // unpack(k) runs on a helper thread beside pack(k+2); it must be finished before the download of sub-batch k+2
+    // is enqueued (same host slab)
+    std::future<void> unpacking[2];
     for (size_t it = 0; it < nsub + 2; ++it) {
         if (it >= 2) {                                            // drain sub-batch it-2 (frees slab set it&1)
             const size_t k = it - 2, first = k * S, cnt = std::min(S, batch - first);
             HX_CHECK(hipEventSynchronize(c->ev_down[k & 1]));
-            unpack(first, cnt, h_out(k));
+            const char* src = h_out(k);
+            unpacking[k & 1] = std::async(std::launch::async, [&unpack, first, cnt, src] { unpack(first, cnt, src); });
         }
         if (it < nsub) {
             const size_t first = it * S, cnt = std::min(S, batch - first);
@@ -402,20 +473,22 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
             HX_CHECK(hipEventRecord(c->ev_up[it & 1], c->s_up));
             HX_CHECK(hipStreamWaitEvent(c->stream, c->ev_up[it & 1], 0));
             rc = compute(cnt, d_in(it), d_out(it));
-            if (rc) return rc;
+            if (rc) break;
             HX_CHECK(hipEventRecord(c->ev_comp[it & 1], c->stream));
             HX_CHECK(hipStreamWaitEvent(c->s_down, c->ev_comp[it & 1], 0));
+            if (unpacking[it & 1].valid()) unpacking[it & 1].get();
             HX_CHECK(hipMemcpyAsync(h_out(it), d_out(it), cnt * (sh.in_place ? sh.in1 : sh.out1), hipMemcpyDeviceToHost,
                                     c->s_down));
             HX_CHECK(hipEventRecord(c->ev_down[it & 1], c->s_down));
         }
     }
-    return 0;
+    for (auto& f : unpacking) if (f.valid()) f.get();
+    return rc;
 }
 
-static size_t sub_batch_for(size_t bytes_per_item) {              // ~64 MB slabs keep all three stages busy
+static size_t sub_batch_for(size_t bytes_per_item) {              // ~32 MB slabs keep all stages busy
     const char* e = getenv("HEXL_HOST_SUB_MB");
-    const size_t target = (e ? (size_t)atoi(e) : 64) << 20;
+    const size_t target = (e ? (size_t)atoi(e) : 32) << 20;
     return std::max<size_t>(1, target / std::max<size_t>(1, bytes_per_item));
 }
 
