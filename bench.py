@@ -193,7 +193,12 @@ def main():
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "alg_bytes_per_launch": alg * a.batch,
                            "kernel": "keyswitch pipeline (k_ksf_up + k_ksf_mac + k_ksf_intt_sp + k_ksf_moddown)",
-                           "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps}
+                           "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps,
+                           # the pipeline runs in chunks of 256 keyswitches; per chunk, from hipEvents on the launch
+                           # stream (compare avg_us of the same kernels in profiles/*kernel_trace*)
+                           "dominant_kernel": {"name": "k_ksf_up (steps 1-2)", "ms_per_chunk": stage[1],
+                                               "share_of_pipeline": stage[1] / stage[0],
+                                               "chunk": min(a.batch, 256)}}
         extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "steps_1_2_inverse_and_modup": stage[1],
                                                              "steps_3_4_mac_and_special_inverse": stage[2],
                                                              "steps_5_7_moddown": stage[3]},

@@ -217,10 +217,12 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     // chunks alternate between two lanes; a batch that fits one chunk is still split in two when it is large
     // enough to fill the chip twice, so the lanes always have something to overlap. Timing runs (ev) stay on one lane.
     size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
-    // (FP64 path: with one barrier per transform and steps 1-2 fused the lanes measure the same as one stream, so a
-    // batch that fits one chunk stays whole -- halves would fall below the fused kernel's threshold)
-    const bool two_lanes = !ev && batch >= 64 && !(getenv("HEXL_KS_ONE_LANE") && atoi(getenv("HEXL_KS_ONE_LANE")) == 1) &&
-                           !(p->use_f64 && batch <= chunk);
+    // (FP64 path: with one barrier per transform and steps 1-2 fused, two lanes measure the same as one stream
+    // (160 k vs 162 k keyswitch/s), so it runs its chunks back to back on the caller's stream; HEXL_KS_ONE_LANE=0
+    // brings the lanes back)
+    const char* lane_env = getenv("HEXL_KS_ONE_LANE");
+    const bool one_lane = lane_env ? atoi(lane_env) == 1 : p->use_f64;
+    const bool two_lanes = !ev && batch >= 64 && !one_lane && !(p->use_f64 && batch <= chunk);
     if (two_lanes && batch <= chunk) chunk = (batch + 1) / 2;
     const size_t lane_words = chunk * scratch_words(p) * p->n;
     if (p->cap < chunk) {
