@@ -136,3 +136,30 @@ def test_fused_and_per_transform_modup_agree(hx, ctx, dev, orc, monkeypatch, n, 
     for b in range(nb):
         assert np.array_equal(outs[0][b], want[b % 3]), f"fused, instance {b}"
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_repeated_launches_are_bit_identical(hx, ctx, dev, orc):
+    """the transforms synchronise with one s_barrier and wave-private LDS re-deals: a race would show up as a rare
+    run-to-run difference (tools/soak.py runs the long version)"""
+    import torch
+    n, L, K, nb = 16384, 7, 8, 160
+    case = KsCase(orc, n, L, K, seed=21)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    distinct = [case.inputs(orc, b) for b in range(2)]
+    ts = np.concatenate([distinct[b % 2][0] for b in range(nb)])
+    rs = np.concatenate([distinct[b % 2][1] for b in range(nb)])
+    d_t, d_r0 = hx.as_i64(ts).to(dev), hx.as_i64(rs).to(dev)
+    ref = None
+    for _ in range(12):
+        d_r = d_r0.clone()
+        plan.keyswitch(d_r, d_t, nb)
+        ctx.sync()
+        if ref is None:
+            ref = d_r.clone()
+            out = hx.to_u64(d_r).reshape(nb, -1)
+            assert np.array_equal(out[0], case.expected(orc, *distinct[0]))
+            assert np.array_equal(out[nb - 1], case.expected(orc, *distinct[(nb - 1) % 2]))
+        else:
+            assert torch.equal(ref, d_r)
+    plan.close()
