@@ -77,3 +77,35 @@ def test_reference_keyswitch_benchmark(tmp_path):
     out = subprocess.run([str(exe), "--benchmark_min_time=0.05"], capture_output=True, text=True, timeout=1800, env=env)
     print(out.stdout[-1500:], out.stderr[-500:])
     assert out.returncode == 0 and "16384_6_7_7_2" in out.stdout
+
+
+# The reference's tests/micro_*.sh and benchmark/micro_*.sh run the same binaries under a matrix of environment
+# settings (FPGA_BITSTREAM / FPGA_KERNEL select a bitstream, BATCH_SIZE_* the FPGA-side batching, N the keyswitch vector
+# size, RUN_CHOICE the backend). This library has one backend and batches by itself; the variables must be accepted
+# and must not change any result. Same matrix, written out here (the scripts need `aocl` and cannot travel).
+ENV_MATRIX = [
+    ("test_fwd_ntt", {"FPGA_KERNEL": "NTT"}),
+    ("test_fwd_ntt", {"FPGA_KERNEL": "NTT", "BATCH_SIZE_NTT": "8"}),
+    ("test_inv_ntt", {"FPGA_KERNEL": "INTT", "BATCH_SIZE_INTT": "8"}),
+    ("test_dyadic_multiply", {"FPGA_KERNEL": "DYADIC_MULTIPLY", "BATCH_SIZE_DYADIC_MULTIPLY": "8"}),
+    ("test_keyswitch", {"FPGA_KERNEL": "KEYSWITCH", "N": "16384", "BATCH_SIZE_KEYSWITCH": "2"}),
+    ("test_keyswitch", {"FPGA_KERNEL": "KEYSWITCH", "N": "8192", "BATCH_SIZE_KEYSWITCH": "1"}),
+    ("test_dyadic_multiply_keyswitch", {"FPGA_KERNEL": "DYADIC_MULTIPLY_KEYSWITCH", "BATCH_SIZE_DYADIC_MULTIPLY": "2",
+                                        "BATCH_SIZE_KEYSWITCH": "2"}),
+]
+
+
+@pytest.mark.parametrize("exe,extra", ENV_MATRIX, ids=[f"{e}-{'-'.join(f'{k}={v}' for k, v in x.items() if k != 'FPGA_KERNEL')}" for e, x in ENV_MATRIX])
+def test_reference_env_matrix(tmp_path, exe, extra):
+    path = BUILD / exe
+    if not path.exists():
+        pytest.skip("reference test sources were not built on this box")
+    import os
+    env = dict(os.environ, RUN_CHOICE="2", FPGA_BITSTREAM="/nonexistent/libkernel.so", **extra)
+    if "keyswitch" in exe:
+        n = int(extra.get("N", "16384"))
+        _vectors(tmp_path, n, [(6, 7, 7)] if "dyadic" in exe else [(6, 7, 7), (5, 7, 6)], count=2)
+        env["KEYSWITCH_DATA_DIR"] = str(tmp_path)
+    out = subprocess.run([str(path)], capture_output=True, text=True, timeout=1800, env=env)
+    print(out.stdout[-1200:], out.stderr[-400:])
+    assert out.returncode == 0 and "[  PASSED  ]" in out.stdout
