@@ -98,8 +98,8 @@ def _check(rc: int, what: str):
 
 
 def ptr_array(arrays):
-    """ctypes array of host pointers to numpy arrays (kept alive by the caller)"""
-    return (_vp * len(arrays))(*[a.ctypes.data for a in arrays])
+    """ctypes array of pointers to numpy arrays (host) or torch tensors (device), kept alive by the caller"""
+    return (_vp * len(arrays))(*[_ptr(a) for a in arrays])
 
 
 def _ptr(t) -> int:
@@ -192,8 +192,8 @@ class KeySwitchPlan:
 
     def keyswitch_host(self, results, t_targets):
         n = len(results)
-        r = (_vp * n)(*[a.ctypes.data for a in results])
-        t = (_vp * n)(*[a.ctypes.data for a in t_targets])
+        r = (_vp * n)(*[_ptr(a) for a in results])
+        t = (_vp * n)(*[_ptr(a) for a in t_targets])
         _check(lib().hexl_keyswitch_host(self.h, r, t, n), "hexl_keyswitch_host")
 
     def time_stages(self, result, t_target, batch: int, iters: int):

@@ -47,6 +47,7 @@ extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_shared) (void)hipFree(c->d_shared);
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->d_ntt_tab) (void)hipFree(c->d_ntt_tab);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -331,6 +332,9 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 #include <functional>
 #include <thread>
 #include <future>
+#include <initializer_list>
+#include <utility>
+#include <vector>
 #include <deque>
 #include <mutex>
 #include <condition_variable>
@@ -492,12 +496,52 @@ static size_t sub_batch_for(size_t bytes_per_item) {              // ~32 MB slab
     return std::max<size_t>(1, target / std::max<size_t>(1, bytes_per_item));
 }
 
+// ------------------------------------------------------------------------------- device-resident callers
+// The reference's API takes plain pointers; callers that already keep their ciphertexts in device (or managed)
+// memory can pass those pointers to the same entry points: no staging, the kernels run where the data lies.
+// All payload pointers of one call must be of the same kind; small shared arrays (tables, moduli) may be either.
+static bool on_device(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain host memory
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+// 0: every pointer is host memory, 1: every pointer is device memory, -1: mixed
+static int payload_kind(std::initializer_list<std::pair<const void* const*, size_t>> lists) {
+    size_t dev = 0, total = 0;
+    for (auto& l : lists)
+        for (size_t i = 0; i < l.second; ++i) { dev += on_device(l.first[i]) ? 1 : 0; ++total; }
+    return dev == 0 ? 0 : dev == total ? 1 : -1;
+}
+// a device copy of a small shared array that may live on either side (`slot` = which quarter of the scratch)
+static int shared_to_device(hexl_ctx* c, const void* src, size_t bytes, int slot, const void** out) {
+    if (on_device(src)) { *out = src; return 0; }
+    const size_t quarter = (bytes + 255) & ~size_t(255);
+    int rc = hx_reserve_device(c, &c->d_shared, &c->d_shared_bytes, 4 * quarter);
+    if (rc) return rc;
+    char* dst = (char*)c->d_shared + slot * quarter;
+    HX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    *out = dst;
+    return 0;
+}
+
 extern "C" int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch, const uint64_t* h_roots,
                                  const uint64_t* h_precon, uint64_t q, uint64_t n) {
     if (!c || !h_x || !h_roots || !h_precon || !supported_ntt_n(n)) return HEXL_E_BADARG;
     if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
     const size_t one = n * 8;
+    const int kind = payload_kind({{(const void* const*)h_x, batch}});
+    if (kind < 0) return HEXL_E_BADARG;
+    if (kind == 1) {                                               // device-resident polynomials: maximal contiguous runs
+        const void *dr, *dp;
+        int rc = shared_to_device(c, h_roots, one, 0, &dr);
+        if (!rc) rc = shared_to_device(c, h_precon, one, 1, &dp);
+        for (size_t i = 0, j; !rc && i < batch; i = j) {
+            for (j = i + 1; j < batch && h_x[j] == h_x[j - 1] + n; ++j) {}
+            rc = hexl_ntt_fwd(c, h_x[i], j - i, (const u64*)dr, (const u64*)dp, q, n);
+        }
+        return rc ? rc : (int)hipStreamSynchronize(c->stream);
+    }
     PipeShape sh{one, one, 2 * one, sub_batch_for(one), true};
     return run_pipeline(c, batch, sh,
         [&](char* h) { memcpy(h, h_roots, one); memcpy(h + one, h_precon, one); },
@@ -512,6 +556,18 @@ extern "C" int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* const* h_x, size_t batch
     if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
     const size_t one = n * 8;
+    const int kind = payload_kind({{(const void* const*)h_x, batch}});
+    if (kind < 0) return HEXL_E_BADARG;
+    if (kind == 1) {
+        const void *dr, *dp;
+        int rc = shared_to_device(c, h_ir, one, 0, &dr);
+        if (!rc) rc = shared_to_device(c, h_ip, one, 1, &dp);
+        for (size_t i = 0, j; !rc && i < batch; i = j) {
+            for (j = i + 1; j < batch && h_x[j] == h_x[j - 1] + n; ++j) {}
+            rc = hexl_ntt_inv(c, h_x[i], j - i, (const u64*)dr, (const u64*)dp, q, inv_n, inv_n_w, n);
+        }
+        return rc ? rc : (int)hipStreamSynchronize(c->stream);
+    }
     PipeShape sh{one, one, 2 * one, sub_batch_for(one), true};
     return run_pipeline(c, batch, sh,
         [&](char* h) { memcpy(h, h_ir, one); memcpy(h + one, h_ip, one); },
@@ -527,6 +583,34 @@ extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* h_out, co
     if (!batch) return 0;
     HX_CHECK(hipSetDevice(c->device));
     const size_t op1 = 2 * n_moduli * n * 8, out1 = 3 * n_moduli * n * 8, mod1 = n_moduli * 8;
+    const int kind = payload_kind({{(const void* const*)h_out, batch}, {(const void* const*)h_a, batch},
+                                   {(const void* const*)h_b, batch}});
+    if (kind < 0) return HEXL_E_BADARG;
+    if (kind == 1) {                                               // device-resident operands and results
+        int rc = 0;
+        for (size_t i = 0, j; !rc && i < batch; i = j) {
+            for (j = i + 1; j < batch && h_out[j] == h_out[j - 1] + out1 / 8 && h_a[j] == h_a[j - 1] + op1 / 8 &&
+                            h_b[j] == h_b[j - 1] + op1 / 8; ++j) {}
+            // per-item moduli: gather the run's lists into one device array
+            std::vector<u64> mods((j - i) * n_moduli);
+            bool dev_mod = on_device(h_moduli[i]);
+            const void* dm = nullptr;
+            if (dev_mod) {                                         // must then be one contiguous device array, too
+                for (size_t k = i + 1; k < j; ++k) dev_mod = dev_mod && h_moduli[k] == h_moduli[k - 1] + n_moduli;
+                if (!dev_mod) return HEXL_E_BADARG;
+                dm = h_moduli[i];
+            } else {
+                for (size_t k = i; k < j; ++k) memcpy(&mods[(k - i) * n_moduli], h_moduli[k], mod1);
+                rc = hx_reserve_device(c, &c->d_shared, &c->d_shared_bytes, mods.size() * 8);
+                if (rc) return rc;
+                HX_CHECK(hipMemcpy(c->d_shared, mods.data(), mods.size() * 8, hipMemcpyHostToDevice));
+                dm = c->d_shared;
+            }
+            rc = hexl_dyadic_multiply(c, h_out[i], h_a[i], h_b[i], j - i, n, (const u64*)dm, n_moduli);
+            if (!rc) rc = (int)hipStreamSynchronize(c->stream);    // d_shared is reused by the next run
+        }
+        return rc;
+    }
     const size_t in1 = 2 * op1 + ((mod1 + 15) & ~size_t(15));   // per item: [a | b | moduli(padded)]
     PipeShape sh{in1, out1, 0, sub_batch_for(in1 + out1), false};
     // layout inside a slab holding cnt items: a[cnt] | b[cnt] | moduli[cnt] (contiguous batches for the kernel);
@@ -554,6 +638,20 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
     HX_CHECK(hipSetDevice(c->device));
     const size_t n = p->n, L = p->L;
     const size_t tt = L * n * 8, rs = 2 * tt;
+    const int kind = payload_kind({{(const void* const*)h_results, batch}, {(const void* const*)h_t_targets, batch}});
+    if (kind < 0) return HEXL_E_BADARG;
+    if (kind == 1) {
+        // device-resident ciphertexts: the kernels accumulate straight into `result`. A run ends where the arrays stop
+        // being contiguous or a result array repeats (two instances of one launch must not update the same words;
+        // launches on one stream are ordered, which keeps the reference's submission-order semantics)
+        int rc = 0;
+        for (size_t i = 0, j; !rc && i < batch; i = j) {
+            for (j = i + 1; j < batch && h_results[j] == h_results[j - 1] + rs / 8 &&
+                            h_t_targets[j] == h_t_targets[j - 1] + tt / 8; ++j) {}
+            rc = hexl_keyswitch(p, h_results[i], h_t_targets[i], j - i);
+        }
+        return rc ? rc : (int)hipStreamSynchronize(c->stream);
+    }
     PipeShape sh{tt, rs, 0, sub_batch_for(tt + rs), false};
     // Like the reference, the device produces the keyswitch output only (the kernels accumulate into a zeroed
     // buffer) and the HOST adds it into the caller's result in submission order

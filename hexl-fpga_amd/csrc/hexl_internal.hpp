@@ -30,6 +30,7 @@ struct hexl_ctx {
     int num_cu = 0;
     // grow-only device scratch + pinned staging used by the *_host entry points
     void* d_stage = nullptr;  size_t d_stage_bytes = 0;
+    void* d_shared = nullptr; size_t d_shared_bytes = 0;   // small shared arrays of device-resident callers
     void* h_stage = nullptr;  size_t h_stage_bytes = 0;
     // host-pointer pipeline: copy streams + events (created lazily), see run_pipeline() in capi.hip
     hipStream_t s_up = nullptr, s_down = nullptr;

@@ -1,6 +1,8 @@
 """GPU: the host-side mirror of host/inc/hexl-fpga.h (set_worksize_X / X / XCompleted) end to end with
 host pointers -- reads like the reference's gtests (tests/test_fwd_ntt.cpp:27-58,
 tests/test_dyadic_multiply.cpp:87-147, tests/test_keyswitch.cpp:122-146)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -95,3 +97,71 @@ def test_argument_checks(api, orc):
         api._NTT(x, x, x, 97, 512)
     with pytest.raises(ValueError):
         api.KeySwitch(x, x, 16384, 6, 7, 7, 3, x, [x], x)
+
+
+# ---- device-resident callers: the same per-object-pointer entry points with device pointers (no staging) ----------
+
+def test_device_pointers_ntt_round_trip(hx, ctx, dev, orc):
+    import torch
+    n, q = 16384, orc.primes(1, 51, 16384)[0]
+    tb = orc.HexlTables(n, q)
+    xs = np.stack([stimulus("RANDOM", n, q, seed=40 + s) for s in range(6)])
+    d = hx.as_i64(xs).to(dev)                                      # one contiguous device array ...
+    lone = hx.as_i64(xs[5].copy()).to(dev)                         # ... and one polynomial somewhere else
+    objs = [d[i] for i in range(5)] + [lone]
+    lib = hx.lib()
+    rc = lib.hexl_ntt_fwd_host(ctx.h, hx.ptr_array(objs), len(objs), tb.roots.ctypes.data, tb.precon.ctypes.data, q, n)
+    assert rc == 0
+    got = np.vstack([hx.to_u64(d)[:5], hx.to_u64(lone)[None, :]])
+    assert np.array_equal(got, orc.ntt_fwd(xs, tb))
+    # tables may be device-resident too
+    ir, ip = hx.as_i64(tb.inv_roots).to(dev), hx.as_i64(tb.inv_precon).to(dev)
+    rc = lib.hexl_ntt_inv_host(ctx.h, hx.ptr_array(objs), len(objs), ir.data_ptr(), ip.data_ptr(), q, tb.inv_n, tb.inv_n_w, n)
+    assert rc == 0
+    back = np.vstack([hx.to_u64(d)[:5], hx.to_u64(lone)[None, :]])
+    assert np.array_equal(back, xs)
+    # mixing host and device payload pointers in one call is refused
+    host_x = xs[0].copy()
+    mixed = (ctypes.c_void_p * 2)(objs[0].data_ptr(), host_x.ctypes.data)
+    assert lib.hexl_ntt_fwd_host(ctx.h, mixed, 2, tb.roots.ctypes.data, tb.precon.ctypes.data, q, n) != 0
+
+
+def test_device_pointers_keyswitch_accumulates_in_place(hx, ctx, dev, orc):
+    n, L, K = 4096, 3, 4
+    case = KsCase(orc, n, L, K, seed=77)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    ins = [case.inputs(orc, b) for b in range(3)]
+    d_t = hx.as_i64(np.concatenate([t for t, _ in ins])).to(dev)
+    d_r = hx.as_i64(np.concatenate([r for _, r in ins])).to(dev)
+    tt, rs = L * n, 2 * L * n
+    # instances 0 and 1 as one contiguous run, then instance 1 AGAIN on the same result array (ordered accumulation),
+    # then instance 2
+    order = [0, 1, 1, 2]
+    plan.keyswitch_host([d_r[b * rs:(b + 1) * rs] for b in order], [d_t[b * tt:(b + 1) * tt] for b in order])
+    out = hx.to_u64(d_r).reshape(3, -1)
+    e = [case.expected(orc, t, r) for t, r in ins]
+    assert np.array_equal(out[0], e[0]) and np.array_equal(out[2], e[2])
+    assert np.array_equal(out[1], case.expected(orc, ins[1][0], e[1]))       # applied twice
+    plan.close()
+
+
+def test_device_pointers_dyadic(hx, ctx, dev, orc):
+    n, nm, num = 4096, 2, 3
+    mod = np.array(orc.primes(nm, 40, n), dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    def operand():                                                 # [2][n_moduli][n], limb m below moduli[m]
+        return np.stack([np.stack([rng.integers(0, int(q), n, dtype=np.uint64) for q in mod]) for _ in range(2)]).reshape(-1)
+    a = np.stack([operand() for _ in range(num)])
+    b = np.stack([operand() for _ in range(num)])
+    d_a, d_b = hx.as_i64(a).to(dev), hx.as_i64(b).to(dev)
+    import torch
+    d_o = torch.zeros((num, 3 * nm * n), dtype=torch.int64, device=dev)
+    lib = hx.lib()
+    mods = [mod.copy() for _ in range(num)]
+    rc = lib.hexl_dyadic_multiply_host(ctx.h, hx.ptr_array([d_o[i] for i in range(num)]), hx.ptr_array([d_a[i] for i in range(num)]),
+                                       hx.ptr_array([d_b[i] for i in range(num)]), num, n, hx.ptr_array(mods), nm)
+    assert rc == 0
+    got = hx.to_u64(d_o)
+    for i in range(num):
+        assert np.array_equal(got[i], orc.dyadic(a[i], b[i], n, mod))
