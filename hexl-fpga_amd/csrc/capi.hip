@@ -85,7 +85,8 @@ extern "C" int hexl_ctx_describe(hexl_ctx* c, char* buf, size_t len) {
 }
 
 // ------------------------------------------------------------------------------- K1..K3
-static bool supported_ntt_n(u64 n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+// 1024..16384 as the reference (keyswitch) / 16384 (NTT); 32768 is beyond its envelope
+static bool supported_ntt_n(u64 n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384 || n == 32768; }
 
 extern "C" int hexl_ntt_fwd(hexl_ctx* c, uint64_t* x, size_t batch, const uint64_t* roots, const uint64_t* precon,
                             uint64_t q, uint64_t n) {
@@ -193,6 +194,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
     // FP64 path: every modulus below 2^52 (the reference's own bound); HEXL_KS_INT=1 forces the integer kernels
     bool f64_ok = !(getenv("HEXL_KS_INT") && atoi(getenv("HEXL_KS_INT")) == 1);
     for (u64 i = 0; i < K; ++i) f64_ok = f64_ok && h_moduli[i] < (1ULL << 52);
+    if (logn == 15 && !f64_ok) { delete p; return HEXL_E_BADARG; }    // N = 32768: FP64 kernels only (moduli < 2^52)
     p->use_f64 = f64_ok;
     p->f64_lazy = 0;
     if (f64_ok && !(getenv("HEXL_KS_NOLAZY") && atoi(getenv("HEXL_KS_NOLAZY")) == 1)) {

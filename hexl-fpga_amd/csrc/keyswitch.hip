@@ -170,23 +170,23 @@ static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_
     static bool attr_set = false;
     if (!attr_set) {
         HX_CHECK(hipFuncSetAttribute((const void*)k_ks_intt<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)G::LDS_BYTES));
+                                     (int)G::LDS_USED));
         HX_CHECK(hipFuncSetAttribute((const void*)k_ks_modup<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)G::LDS_BYTES));
+                                     (int)G::LDS_USED));
         HX_CHECK(hipFuncSetAttribute((const void*)k_ks_moddown<LOGN, LOGE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
         attr_set = true;
     }
     hipStream_t st = p->cur;
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1)
-        hipLaunchKernelGGL((k_ks_intt<LOGN, LOGE>), dim3(a.nb * a.L), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ks_intt<LOGN, LOGE>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2)
-        hipLaunchKernelGGL((k_ks_modup<LOGN, LOGE>), dim3(a.nb * (a.L + 1)), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ks_modup<LOGN, LOGE>), dim3(a.nb * (a.L + 1)), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ks_moddown<LOGN, LOGE>), dim3(a.nb * a.L * 2), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ks_moddown<LOGN, LOGE>), dim3(a.nb * a.L * 2), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }

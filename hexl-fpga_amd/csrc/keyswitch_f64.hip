@@ -239,10 +239,16 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     // prod is requested right after the cross-wave re-deal and lands during the remaining passes; result is
     // requested first thing in the epilogue and lands during the (prod - w) * msf multiplications
     double pv[G::E];
-    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {        // |w| <= 2.14p: |prod - w| <= 2.64p below
+    if constexpr (G::HALF_ONLY) {                                  // N = 32768: no registers to hold prod during the transform
+        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
-    });
+    } else {
+        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {    // |w| <= 2.14p: |prod - w| <= 2.64p below
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
+        });
+    }
     const u32 tB = u32(G::idxB(0, tid));
     u64 old[G::E];
 #pragma unroll
@@ -268,11 +274,11 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     using G = Geom<LOGN, LOGE>;
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_BYTES);
-        if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE, LAZY>, G::LDS_BYTES);
+        int rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_USED);
+        if (!rc) rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
+        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_USED);
+        if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_USED);
+        if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE, LAZY>, G::LDS_USED);
         if (rc) return rc;
         attr_set = true;
     }
@@ -285,15 +291,15 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     // than the two kernels below: its epilogue loads cannot be requested early, tools/experiments/fused_down.patch)
     static int fuse = -1;
     if (fuse < 0) { const char* e = getenv("HEXL_KS_FUSE"); fuse = e ? atoi(e) : 1; }
-    const bool fused_up = (fuse & 1) && nb * L >= 2 * cus;
+    const bool fused_up = (fuse & 1) && nb * L >= 2 * cus && !G::HALF_ONLY;   // N = 32768: 64 VGPRs of data already
     // timing stages: 1 = steps 1-2 (inverse + mod-up transforms), 2 = steps 3-4, 4 = steps 5-7
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1) {
         if (fused_up) {
-            hipLaunchKernelGGL((k_ksf_up<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
+            hipLaunchKernelGGL((k_ksf_up<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_USED, st, a);
         } else {
-            hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_BYTES, st, a);
-            hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * L * L), dim3(G::T), G::LDS_BYTES, st, a);
+            hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_USED, st, a);
+            hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * L * L), dim3(G::T), G::LDS_USED, st, a);
         }
     }
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
@@ -302,11 +308,11 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
         const u32 by = nb < 8 ? nb : 8;                            // 8 batch lanes keep >= 2048 workgroups in flight
         if (L <= 8) hipLaunchKernelGGL((k_ksf_mac<8>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);
         else        hipLaunchKernelGGL((k_ksf_mac<16>), dim3(threads / 256, by), dim3(256), 0, st, a, (u32)G::N);
-        hipLaunchKernelGGL((k_ksf_intt_sp<LOGN, LOGE, LAZY>), dim3(nb * 2), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_intt_sp<LOGN, LOGE, LAZY>), dim3(nb * 2), dim3(G::T), G::LDS_USED, st, a);
     }
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ksf_moddown<LOGN, LOGE, LAZY>), dim3(nb * L * 2), dim3(G::T), G::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((k_ksf_moddown<LOGN, LOGE, LAZY>), dim3(nb * L * 2), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }
@@ -332,6 +338,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
             case 11: return run_chunk_f64<11, 5, 3>(p, a, stage_mask, ev);
             case 12: return run_chunk_f64<12, 5, 3>(p, a, stage_mask, ev);
             case 13: return run_chunk_f64<13, 5, 3>(p, a, stage_mask, ev);
+            case 15: return run_chunk_f64<15, 5, 3>(p, a, stage_mask, ev);      // beyond the reference: N = 32768
             case 14: return p->f64_lazy == 12 ? run_chunk_f64<14, 4, 12>(p, a, stage_mask, ev)
                           : p->f64_lazy == 6 ? run_chunk_f64<14, 4, 6>(p, a, stage_mask, ev)
                                              : run_chunk_f64<14, 4, 3>(p, a, stage_mask, ev);
@@ -343,6 +350,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
         case 11: return run_chunk_f64<11, 5, 0>(p, a, stage_mask, ev);
         case 12: return run_chunk_f64<12, 5, 0>(p, a, stage_mask, ev);
         case 13: return run_chunk_f64<13, 5, 0>(p, a, stage_mask, ev);
+        case 15: return run_chunk_f64<15, 5, 0>(p, a, stage_mask, ev);
         case 14: return run_chunk_f64<14, 4, 0>(p, a, stage_mask, ev);
         default: return HEXL_E_BADARG;
     }

@@ -225,10 +225,10 @@ static int launch_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
     static bool attr_set = false;
     if (!attr_set) {
         HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd<LOGN, LOGE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ntt_fwd<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_BYTES, ctx->stream, x,
+    hipLaunchKernelGGL((k_ntt_fwd<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, (u32)batch);
     return (int)hipGetLastError();
 }
@@ -240,10 +240,10 @@ static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
     static bool attr_set = false;
     if (!attr_set) {
         HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv<LOGN, LOGE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ntt_inv<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_BYTES, ctx->stream, x, ir,
+    hipLaunchKernelGGL((k_ntt_inv<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x, ir,
                        ip, q, a, ap, b, bp, (u32)batch);
     return (int)hipGetLastError();
 }
@@ -255,10 +255,10 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
     static bool attr_set = false;
     if (!attr_set) {
         HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_x<LOGN, LOGE, LAZY>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_BYTES, ctx->stream, x,
+    hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, w, wp, viol, (u32)batch);
     return (int)hipGetLastError();
 }
@@ -270,10 +270,10 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     static bool attr_set = false;
     if (!attr_set) {
         HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_x<LOGN, LOGE, LAZY>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_BYTES, ctx->stream, x,
+    hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
     return (int)hipGetLastError();
 }
@@ -287,6 +287,7 @@ static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64
         case 12: return launch_fwd_x<12, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
         case 13: return launch_fwd_x<13, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
         case 14: return launch_fwd_x<14, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 15: return launch_fwd_x<15, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);    // beyond the reference: half-size exchanges
         default: return HEXL_E_BADARG;
     }
 }
@@ -299,6 +300,7 @@ static int dispatch_inv_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64
         case 12: return launch_inv_x<12, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
         case 13: return launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
         case 14: return launch_inv_x<14, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 15: return launch_inv_x<15, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
         default: return HEXL_E_BADARG;
     }
 }
@@ -330,6 +332,7 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
         case 14:
             return hx_loge_for(14) == 4 ? launch_fwd<14, 4>(ctx, x, batch, roots, precon, q)
                                         : launch_fwd<14, 5>(ctx, x, batch, roots, precon, q);
+        case 15: return launch_fwd<15, 5>(ctx, x, batch, roots, precon, q);
         default: return HEXL_E_BADARG;
     }
 }
@@ -357,6 +360,7 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
         case 14:
             return hx_loge_for(14) == 4 ? launch_inv<14, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp)
                                         : launch_inv<14, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
+        case 15: return launch_inv<15, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
         default: return HEXL_E_BADARG;
     }
 }

@@ -84,6 +84,12 @@ struct Geom {
     // +16 words per 512 puts consecutive 512-word runs on opposite bank halves.
     static constexpr int LDS_WORDS = N + (N >> 4) + ((N >> 9) << 4);
     static constexpr size_t LDS_BYTES = size_t(LDS_WORDS) * 8;
+    // half-size exchange (redeal_half): N/2 words, same padding rule. N = 32768 does not fit the CU's 160 KiB of
+    // LDS in one piece and always uses it (HALF_ONLY).
+    static constexpr int LDS_HALF_WORDS = (N >> 1) + (N >> 5) + ((N >> 10) << 4);
+    static constexpr size_t LDS_HALF_BYTES = size_t(LDS_HALF_WORDS) * 8;
+    static constexpr bool HALF_ONLY = LDS_BYTES > 160 * 1024;
+    static constexpr size_t LDS_USED = HALF_ONLY ? LDS_HALF_BYTES : LDS_BYTES;
 
     static constexpr int LOGT = LOGN - LOGE;
     static constexpr int WB = LOGT < 6 ? LOGT : 6;         // thread-index bits that are lane bits
@@ -219,6 +225,83 @@ __device__ __forceinline__ void redeal_x(V (&v)[G::E], V* lds, int tid, FromIdx 
     if constexpr (PRIVATE) wave_fence();
 }
 
+// Half-size re-deal: the exchange goes through LDS in two rounds, so a transform needs N/2 words of LDS (N = 32768
+// in 140 KiB). Works between two ownership maps that swap the top register bit with thread bit SEL: coefficient bits
+// (a, b) with a <-> register top bit in `from` and thread bit SEL in `to`, b the other way round. Round h moves the
+// coefficients with bit a XOR bit b == h; for a thread whose bit SEL is t that is register half (h XOR t) under BOTH
+// maps, so every round reads back into the registers it has just sent. Threads with t = 1 swap their register halves
+// before and after, so the LDS traffic itself is the same straight-line code for every lane (only the base addresses
+// depend on t). DROP = max(a, b) is the bit left out of the LDS slot number. SEL >= 6: whole waves take the same
+// side, barriers between the phases (LEAD as in redeal_x; TRAIL because a wave's private block overlaps words other
+// waves read in round 1). SEL < 6: the exchange stays inside the wave, no barriers.
+// (Measured for N = 16384 as a way to fit two workgroups per CU: bit-exact, no faster -- tools/experiments/.)
+template <class G, int DROP>
+__device__ __forceinline__ int half_slot(int idx) {
+    return G::pad(((idx >> (DROP + 1)) << DROP) | (idx & ((1 << DROP) - 1)));
+}
+template <class G, class V>
+__device__ __forceinline__ void swap_halves_if(V (&v)[G::E], bool t) {
+#pragma unroll
+    for (int r = 0; r < G::E / 2; ++r) {
+        const V lo = v[r], hi = v[r + G::E / 2];
+        v[r] = t ? hi : lo;
+        v[r + G::E / 2] = t ? lo : hi;
+    }
+}
+template <class G, int SEL, int DROP, bool LEAD, bool TRAIL, class V, class FromIdx, class ToIdx>
+__device__ __forceinline__ void redeal_half(V (&v)[G::E], V* lds, int tid, FromIdx from, ToIdx to) {
+    constexpr bool PRIVATE = SEL < 6;
+    constexpr int H = G::E / 2;
+    const bool t = (tid >> SEL) & 1;
+    // slot distance between a register and its partner in the other half (the partner bit is clear in at(r < H))
+    const int dfrom = half_slot<G, DROP>(from(H, tid)) - half_slot<G, DROP>(from(0, tid));
+    const int dto = half_slot<G, DROP>(to(H, tid)) - half_slot<G, DROP>(to(0, tid));
+    // physical register r < H holds logical register r + H*t, physical r + H holds logical r + H*(1 - t)
+    V* const wr0 = lds + (t ? dfrom : 0);
+    V* const wr1 = lds + (t ? 0 : dfrom);
+    V* const rd0 = lds + (t ? dto : 0);
+    V* const rd1 = lds + (t ? 0 : dto);
+    swap_halves_if<G>(v, t);
+    if constexpr (PRIVATE) wave_fence();
+    else if constexpr (LEAD) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < H; ++r) wr0[half_slot<G, DROP>(from(r, tid))] = v[r];
+    if constexpr (PRIVATE) wave_fence(); else __syncthreads();
+#pragma unroll
+    for (int r = 0; r < H; ++r) v[r] = rd0[half_slot<G, DROP>(to(r, tid))];
+    if constexpr (PRIVATE) wave_fence(); else __syncthreads();
+#pragma unroll
+    for (int r = 0; r < H; ++r) wr1[half_slot<G, DROP>(from(r, tid))] = v[r + H];
+    if constexpr (PRIVATE) wave_fence(); else __syncthreads();
+#pragma unroll
+    for (int r = 0; r < H; ++r) v[r + H] = rd1[half_slot<G, DROP>(to(r, tid))];
+    if constexpr (PRIVATE) wave_fence();
+    else if constexpr (TRAIL) __syncthreads();
+    swap_halves_if<G>(v, t);
+}
+
+// The re-deal between the full pass on coefficient bits [LO, LO+LOGE) (`idxF<LO>`) and its lower neighbour -- the
+// full pass below it, or the partial pass (B order) when LOWER_IS_B -- in the direction of the transform.
+template <class G, int LO, int LOGE, bool FORWARD, bool LEAD, bool LOWER_IS_B, class V>
+__device__ __forceinline__ void redeal_pass(V (&v)[G::E], V* lds, int tid) {
+    auto upper = [](int r, int t) { return G::template idxF<LO>(r, t); };
+    auto lower = [](int r, int t) {
+        if constexpr (LOWER_IS_B) return G::idxB(r, t);
+        else return G::template idxF<LO - LOGE>(r, t);
+    };
+    if constexpr (G::HALF_ONLY) {
+        // the lower map must carry the top register bit on coefficient bit LO-1: true for a full pass, and for B only
+        // when the partial pass is a full one as well (NG == 1, B == idxF<0>)
+        static_assert(!LOWER_IS_B || (G::NG == 1 && LO == LOGE), "half-size exchange: unsupported geometry");
+        if constexpr (FORWARD) redeal_half<G, LO - 1, LO + LOGE - 1, LEAD, true>(v, lds, tid, upper, lower);
+        else                   redeal_half<G, LO - 1, LO + LOGE - 1, true, false>(v, lds, tid, lower, upper);
+    } else {
+        constexpr bool PRIV = G::template wave_private<LO>;
+        if constexpr (FORWARD) redeal_x<G, PRIV, LEAD>(v, lds, tid, upper, lower);
+        else                   redeal_x<G, PRIV, LEAD>(v, lds, tid, lower, upper);
+    }
+}
+
 template <int LOGN, int LOGE>
 struct WgNtt {
     using G = Geom<LOGN, LOGE>;
@@ -236,16 +319,8 @@ struct WgNtt {
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             fwd_stages<E, 0, LOGE, PASS * LOGE + 1>(v, Gp, roots, precon, q, twoq);
             // hand over to the next pass's ownership
-            constexpr bool PRIV = G::template wave_private<LO>;
             constexpr bool LEAD = !(FRESH && PASS == 0);
-            if constexpr (PASS + 1 < G::P - 1) {
-                constexpr int LO2 = LO - LOGE;
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                                        [](int r, int t) { return G::template idxF<LO2>(r, t); });
-            } else {
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                                        [](int r, int t) { return G::idxB(r, t); });
-            }
+            redeal_pass<G, LO, LOGE, true, LEAD, (PASS + 1 == G::P - 1)>(v, lds, tid);
             fwd_pass<PASS + 1, FRESH>(v, lds, tid, roots, precon, q, twoq);
         } else {
             // partial pass: NG groups of 2^KL contiguous words
@@ -292,16 +367,8 @@ struct WgNtt {
                                                     u64 b, u64 bp) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
-            constexpr bool PRIV = G::template wave_private<LO>;
             constexpr bool LEAD = !(FRESH && PASS == 0);
-            if constexpr (PASS == 0) {
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
-                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
-            } else {
-                constexpr int LOP = LO - LOGE;
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
-                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
-            }
+            redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iroots, iprecon, q, twoq, a, ap, b, bp);
             inv_pass<PASS + 1, FRESH>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp);

@@ -101,16 +101,8 @@ struct WgNttF64 {
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6)>(v, Gp, w, wp, m);
-            constexpr bool PRIV = G::template wave_private<LO>;
             constexpr bool LEAD = !(FRESH && PASS == 0);
-            if constexpr (PASS + 1 < G::P - 1) {
-                constexpr int LO2 = LO - LOGE;
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                                        [](int r, int t) { return G::template idxF<LO2>(r, t); });
-            } else {
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
-                                        [](int r, int t) { return G::idxB(r, t); });
-            }
+            redeal_pass<G, LO, LOGE, true, LEAD, (PASS + 1 == G::P - 1)>(v, lds, tid);
             if constexpr (PASS == 0) after_cross();
             fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m);
         } else {
@@ -170,16 +162,8 @@ struct WgNttF64 {
                                                     const double* iwp, const Mod m, const InvScale sc) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
-            constexpr bool PRIV = G::template wave_private<LO>;
             constexpr bool LEAD = !(FRESH && PASS == 0);
-            if constexpr (PASS == 0) {
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::idxB(r, t); },
-                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
-            } else {
-                constexpr int LOP = LO - LOGE;
-                redeal_x<G, PRIV, LEAD>(v, lds, tid, [](int r, int t) { return G::template idxF<LOP>(r, t); },
-                                        [](int r, int t) { return G::template idxF<LO>(r, t); });
-            }
+            redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6)>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc);

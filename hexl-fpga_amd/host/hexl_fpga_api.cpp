@@ -254,7 +254,7 @@ void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n, 
                const uint64_t* moduli, const uint64_t** k_switch_keys, const uint64_t* modswitch_factors,
                const uint64_t* twiddle_factors) {
     REQUIRE(result && t_target_iter_ptr && moduli && k_switch_keys && modswitch_factors, "KeySwitch: null pointer");
-    REQUIRE(pow2_in(n, 1024, 16384), "KeySwitch: requires n = 16384/8192/4096/2048/1024");   // keyswitch.cpp:23-26
+    REQUIRE(pow2_in(n, 1024, 32768), "KeySwitch: requires n = 32768/16384/8192/4096/2048/1024");   // keyswitch.cpp:23-26
     REQUIRE(decomp_modulus_size > 0 && rns_modulus_size > 0, "KeySwitch: requires decomp/rns modulus size > 0");
     REQUIRE(key_component_count == 2, "KeySwitch: requires key_component_count = 2");
     REQUIRE(decomp_modulus_size < key_modulus_size && key_modulus_size <= 16,
@@ -289,7 +289,7 @@ void _set_worksize_NTT(uint64_t ws) {
 void _NTT(uint64_t* operand, const uint64_t* root_of_unity_powers, const uint64_t* precon_root_of_unity_powers,
           uint64_t coeff_modulus, uint64_t n) {
     REQUIRE(operand && root_of_unity_powers && precon_root_of_unity_powers, "_NTT: null pointer");
-    REQUIRE(pow2_in(n, 1024, 16384), "_NTT: requires n = 16384 (1024..16384 accepted here)");   // ntt.cpp:24
+    REQUIRE(pow2_in(n, 1024, 32768), "_NTT: requires n = 16384 (1024..32768 accepted here)");   // ntt.cpp:24
     Engine& e = eng();
     std::lock_guard<std::mutex> lk(e.mu_ntt);
     e.q_ntt.push_back({operand, root_of_unity_powers, precon_root_of_unity_powers, coeff_modulus, n});
@@ -314,7 +314,7 @@ void _INTT(uint64_t* operand, const uint64_t* inv_root_of_unity_powers,
            const uint64_t* precon_inv_root_of_unity_powers, uint64_t coeff_modulus, uint64_t inv_n, uint64_t inv_n_w,
            uint64_t n) {
     REQUIRE(operand && inv_root_of_unity_powers && precon_inv_root_of_unity_powers, "_INTT: null pointer");
-    REQUIRE(pow2_in(n, 1024, 16384), "_INTT: requires n = 16384 (1024..16384 accepted here)");  // intt.cpp:25
+    REQUIRE(pow2_in(n, 1024, 32768), "_INTT: requires n = 16384 (1024..32768 accepted here)");  // intt.cpp:25
     Engine& e = eng();
     std::lock_guard<std::mutex> lk(e.mu_intt);
     e.q_intt.push_back({operand, inv_root_of_unity_powers, precon_inv_root_of_unity_powers, coeff_modulus, inv_n,

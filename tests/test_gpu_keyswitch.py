@@ -22,7 +22,7 @@ def run_gpu(hx, ctx, dev, case, ts, rs):
 
 
 @pytest.mark.parametrize("n,L,K", [(1024, 1, 2), (1024, 3, 4), (2048, 2, 3), (4096, 5, 7), (8192, 6, 7),
-                                   (16384, 6, 7), (16384, 7, 8), (16384, 2, 7)])
+                                   (16384, 6, 7), (16384, 7, 8), (16384, 2, 7), (32768, 3, 4)])
 def test_vs_oracle(hx, ctx, dev, orc, n, L, K):
     case = KsCase(orc, n, L, K, seed=n + L)
     nb = 3 if n >= 8192 else 5

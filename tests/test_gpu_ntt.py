@@ -110,3 +110,24 @@ def test_full_batch_roundtrip_and_linearity(hx, ctx, dev, orc):
     ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
     ctx.sync()
     assert torch.equal(d.cpu().reshape(-1), hx.as_i64(x).reshape(-1))
+
+
+@pytest.mark.parametrize("bits", [51, 30, 55])
+def test_n32768_beyond_the_reference_envelope(hx, ctx, dev, orc, bits):
+    """N = 32768: the polynomial does not fit the CU's LDS, every re-deal runs in two half-size rounds
+    (ntt_core.hpp: redeal_half). 51/30-bit primes take the exact FP64 path, 55-bit the integer butterflies; ALL_MAX data
+    forces the per-polynomial integer fallback of the fast-path kernel."""
+    n = 32768
+    q = orc.primes(1, bits, n)[0]
+    tb = orc.HexlTables(n, q)
+    xs = np.stack([stimulus(kind, n, q, seed=3) for kind in ("RANDOM", "RAMP", "ALL_MAX_VALUES", "IMPULSE", "RANDOM")])
+    d = hx.as_i64(xs).to(dev)
+    tabs = [hx.as_i64(a).to(dev) for a in (tb.roots, tb.precon, tb.inv_roots, tb.inv_precon)]
+    ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)
+    ctx.sync()
+    assert np.array_equal(hx.to_u64(d), orc.ntt_fwd(xs, tb))
+    ys = np.stack([stimulus("RANDOM", n, q, seed=9 + i) for i in range(4)])
+    d = hx.as_i64(ys).to(dev)
+    ctx.ntt_inv(d, tabs[2], tabs[3], q, tb.inv_n, tb.inv_n_w, n)
+    ctx.sync()
+    assert np.array_equal(hx.to_u64(d), orc.ntt_inv(ys, tb))

@@ -14,11 +14,11 @@ from ks_util import KsCase
 dev = torch.device("cuda:0")
 ctx = hx.Context(0)
 L, K = 3, 4
-for n in (1024, 2048, 4096, 8192, 16384):
+for n in (1024, 2048, 4096, 8192, 16384, 32768):
     case = KsCase(orc, n, L, K, seed=1)
     plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
     plan.set_keys(case.keys)
-    B = 1024 * (16384 // n)
+    B = max(256, 1024 * 16384 // n)
     distinct = [case.inputs(orc, b) for b in range(4)]
     ts = np.concatenate([distinct[b % 4][0] for b in range(B)])
     rs = np.concatenate([distinct[b % 4][1] for b in range(B)])
