@@ -197,6 +197,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
     if (logn == 15 && !f64_ok) { delete p; return HEXL_E_BADARG; }    // N = 32768: FP64 kernels only (moduli < 2^52)
     p->use_f64 = f64_ok;
     p->f64_lazy = 0;
+    p->f64_loge = ks_loge(logn, true);
     if (f64_ok && !(getenv("HEXL_KS_NOLAZY") && atoi(getenv("HEXL_KS_NOLAZY")) == 1)) {
         double qmax = 0;
         for (u64 i = 0; i < K; ++i) qmax = (double)h_moduli[i] > qmax ? (double)h_moduli[i] : qmax;
@@ -229,6 +230,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         HX_CHECK(hipMalloc((void**)&p->d_mods_f64, K * sizeof(KsModF64)));
         HX_CHECK(hipMalloc((void**)&p->d_tables_f64, ft.size() * sizeof(double)));
         HX_CHECK(hipMalloc((void**)&p->d_keys_f64, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
+        if (logn == 14) HX_CHECK(hipMalloc((void**)&p->d_keys_x, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
         HX_CHECK(hipMemcpy(p->d_mods_f64, fm.data(), K * sizeof(KsModF64), hipMemcpyHostToDevice));
         HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -257,6 +259,7 @@ extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
     if (p->d_mods_f64) (void)hipFree(p->d_mods_f64);
     if (p->d_tables_f64) (void)hipFree(p->d_tables_f64);
     if (p->d_keys_f64) (void)hipFree(p->d_keys_f64);
+    if (p->d_keys_x) (void)hipFree(p->d_keys_x);
     delete p;
     return 0;
 }
@@ -270,9 +273,10 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     const u64 n = p->n, L = p->L, K = p->K;
     const std::vector<u32> perm = ks_perm(p->logn, ks_loge(p->logn, false));
     std::vector<u64> dev(size_t(L) * (L + 1) * 2 * n);
-    std::vector<double> devf;
-    std::vector<u32> permf;
-    if (p->use_f64) { devf.resize(dev.size()); permf = ks_perm(p->logn, ks_loge(p->logn, true)); }
+    std::vector<double> devf, devx;
+    std::vector<u32> permf, permx;
+    if (p->use_f64) { devf.resize(dev.size()); permf = ks_perm(p->logn, p->f64_loge); }
+    if (p->d_keys_x) { devx.resize(dev.size()); p->x_loge = hx_ks_x_loge(); permx = ks_perm(p->logn, p->x_loge); }
     for (u64 d = 0; d < L; ++d) {
         if (!h_keys[d]) return HEXL_E_BADARG;
         for (u64 slot = 0; slot <= L; ++slot) {
@@ -287,6 +291,11 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
                         const u64 v = src[permf[j]] % q;
                         devf[base + j] = v > q / 2 ? (double)v - (double)q : (double)v;
                     }
+                if (p->d_keys_x)
+                    for (u64 j = 0; j < n; ++j) {
+                        const u64 v = src[permx[j]] % q;
+                        devx[base + j] = v > q / 2 ? (double)v - (double)q : (double)v;
+                    }
             }
         }
     }
@@ -294,6 +303,8 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     HX_CHECK(hipMemcpy(p->d_keys, dev.data(), dev.size() * sizeof(u64), hipMemcpyHostToDevice));
     if (p->use_f64)
         HX_CHECK(hipMemcpy(p->d_keys_f64, devf.data(), devf.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (p->d_keys_x)
+        HX_CHECK(hipMemcpy(p->d_keys_x, devx.data(), devx.size() * sizeof(double), hipMemcpyHostToDevice));
     p->have_keys = true;
     return 0;
 }
@@ -462,13 +473,17 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     auto h_out = [&](size_t k) { return h_in(k) + in_slab; };
     auto d_out = [&](size_t k) { return sh.in_place ? d_in(k) + sh.shared : d_in(k) + in_slab; };
     // unpack(k) runs on a helper thread beside pack(k+2); it must be finished before the download of sub-batch k+2
-    // is enqueued (same host slab)
+    // is enqueued (same host slab) and before unpack(k+1) starts (ordering of accumulating unpacks)
     std::future<void> unpacking[2];
     for (size_t it = 0; it < nsub + 2; ++it) {
         if (it >= 2) {                                            // drain sub-batch it-2 (frees slab set it&1)
             const size_t k = it - 2, first = k * S, cnt = std::min(S, batch - first);
             HX_CHECK(hipEventSynchronize(c->ev_down[k & 1]));
             const char* src = h_out(k);
+            // unpacks run strictly one after the other, in submission order: a keyswitch unpack ACCUMULATES into the
+            // caller's result, and the same result may appear in several sub-batches
+            // (benchmark/bench_keyswitch.cpp:113-131). unpack(k) still overlaps pack(k+2) and the copies.
+            if (unpacking[(k + 1) & 1].valid()) unpacking[(k + 1) & 1].get();
             unpacking[k & 1] = std::async(std::launch::async, [&unpack, first, cnt, src] { unpack(first, cnt, src); });
         }
         if (it < nsub) {

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/hexl_mi355x.h"
@@ -22,6 +23,23 @@ typedef unsigned __int128 u128;
             return (int)_e;                                                                  \
         }                                                                                    \
     } while (0)
+
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) applies to the CURRENT device's copy of a kernel, and the
+// launchers may run on one host thread per device (NUM_DEV > 1): one of these per call site runs its initialiser
+// once per device, serialised.
+struct PerDeviceOnce {
+    std::mutex m;
+    uint64_t done = 0;
+    template <class F>
+    int run(int device, F init) {
+        std::lock_guard<std::mutex> g(m);
+        const uint64_t bit = 1ull << (device & 63);
+        if (done & bit) return 0;
+        const int rc = init();
+        if (!rc) done |= bit;
+        return rc;
+    }
+};
 
 struct hexl_ctx {
     int device = 0;
@@ -76,9 +94,12 @@ struct hexl_ks_plan {
     // FP64 path (all moduli < 2^52): same tables / keys as centred doubles
     bool use_f64 = false;
     int f64_lazy = 0;                 // forward reduction period of the lazy kernels (3, 6, 12 by modulus size); 0 = strict
+    u32 f64_loge = 4;                 // elements-per-thread exponent of the FP64 kernels (fixes the keys' B order)
     KsModF64* d_mods_f64 = nullptr;   // [K]
     double* d_tables_f64 = nullptr;   // [K][4][n]
     double* d_keys_f64 = nullptr;     // [L][L+1][2][n]
+    double* d_keys_x = nullptr;       // the same keys in the B order of the slot-major pipeline's geometry (keyswitch_x.hip)
+    u32 x_loge = 5;                   // ... whose elements-per-thread exponent this is
     // scratch for `cap` keyswitches per lane; two lanes (aux streams) work on alternating chunks so that kernels
     // of different kinds -- FP64-bound transforms and the HBM-bound multiply-accumulate -- share the chip and one
     // chunk's ragged last wave of workgroups is filled by the other's
@@ -101,6 +122,11 @@ int hx_launch_keyswitch(hexl_ks_plan*, u64* d_result, const u64* d_t_target, siz
 // one scratch chunk (nb <= plan->cap) on the FP64 path
 int hx_launch_keyswitch_f64(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
                             hipEvent_t* ev);
+// the same on the slot-major pipeline (keyswitch_x.hip; N = 16384, large chunks)
+int hx_launch_keyswitch_x(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
+                          hipEvent_t* ev);
+bool hx_ks_x_applies(const hexl_ks_plan*, size_t nb);
+u32 hx_ks_x_loge();
 // index of coefficient held in register r of thread tid after a forward transform ("B layout")
 u32 hx_idxB(u32 logn, u32 r, u32 tid);
 u32 hx_loge_for(u32 logn);

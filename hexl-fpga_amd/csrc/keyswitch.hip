@@ -167,16 +167,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_moddown(KsArgs a) {
 template <int LOGN, int LOGE>
 static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ks_intt<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)G::LDS_USED));
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ks_modup<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)G::LDS_USED));
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ks_moddown<LOGN, LOGE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = once.run(p->ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ks_intt<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_USED));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ks_modup<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_USED));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ks_moddown<LOGN, LOGE>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+            return 0;
+        }))
+        return rc;
     hipStream_t st = p->cur;
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1)
@@ -255,6 +256,11 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         p->cur = lanes == 2 ? p->aux[lane] : user;                   // one lane: straight on the caller's stream
         p->cur_scratch = p->d_scratch + size_t(lane) * p->cap * scratch_words(p) * n;
         int rc;
+        if (p->use_f64 && hx_ks_x_applies(p, nb)) {
+            rc = hx_launch_keyswitch_x(p, d_result + b0 * 2 * L * n, d_t_target + b0 * L * n, nb, stage_mask, ev);
+            if (rc) return rc;
+            continue;
+        }
         if (p->use_f64) {
             rc = hx_launch_keyswitch_f64(p, d_result + b0 * 2 * L * n, d_t_target + b0 * L * n, nb, stage_mask, ev);
             if (rc) return rc;

@@ -272,16 +272,16 @@ static int set_lds(K kern, size_t bytes) {
 template <int LOGN, int LOGE, int LAZY>
 static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_USED);
-        if (!rc) rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
-        if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_USED);
-        if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_USED);
-        if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE, LAZY>, G::LDS_USED);
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc0 = once.run(p->ctx->device, [] {
+            int rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds(k_ksf_moddown<LOGN, LOGE, LAZY>, G::LDS_USED);
+            return rc;
+        }))
+        return rc0;
     hipStream_t st = p->cur;
     const u32 L = a.L, nb = a.nb;
     // one workgroup per input polynomial (all its transforms back to back) once that alone fills the chip twice;

@@ -1,0 +1,428 @@
+// keyswitch_x.hip -- K4 on the FP64 pipe, SLOT-MAJOR pipeline for large batches (N = 16384): the key
+// multiply-accumulate (device/keyswitch/dyadmult.hpp:85-166) runs in the registers of the
+// workgroup that produced the transforms, as the reference's pipes do -- `u` (15 MB per keyswitch in the (b, d)-major
+// pipeline of keyswitch_f64.hip) and `prod` never exist in memory.
+//
+// One workgroup = 512 threads x 32 coefficients (Geom<14,5>: three register passes, two re-deals), 256 VGPRs per
+// thread: 64 hold the polynomial in flight, 128 the two accumulators (prod[k][slot], k = 0, 1), the rest is working
+// space. Two kernels per chunk of instances:
+//
+//   k_ksx_special (b)       for every d:  c_d = INTT_{q_d}(t_target[d])  -> scratch (canonical doubles, natural order),
+//                                         acc_k += NTT_{q_sp}(c_d mod q_sp) . key[d][special][k]        (steps 1-3)
+//                           then          s'_k = INTT_{q_sp}(acc_k) + floor(q_sp/2)  -> scratch         (step 4)
+//   k_ksx_main (b, i < L)   for every d:  acc_k += NTT_{q_i}(c_d mod q_i) . key[d][i][k]   (d == i: t_target[i] itself)
+//                           then, k = 0, 1:  w = NTT_{q_i}((s'_k + fix_i) mod q_i);
+//                                            result[k][i] += (acc_k - w) . msf_i                        (steps 5-7)
+//
+// HBM-side traffic per keyswitch: t_target twice, c once out and (L2 permitting) once in, s', result in and out --
+// against t_target + 8 L^2 n of u both ways + prod both ways before. Arithmetic and bounds are those of f64_arith.hpp;
+// results are bit-identical to the (b, d)-major pipeline and the integer kernels.
+//
+// Natural-order arrays (t_target, result) meet the transforms' "B" register order through an LDS re-deal (A <-> B):
+// at 32 coefficients per thread a lane owns 16 adjacent words, and direct B-order global access would touch 64
+// cache lines per wave instruction.
+#include <stdlib.h>
+
+#include "hexl_internal.hpp"
+#include "ntt_core_f64.hpp"
+
+using namespace hx;
+
+#ifndef KX_NEXT_MODE
+#define KX_NEXT_MODE 1
+#endif
+#ifndef KX_TF
+#define KX_TF 0      // twiddle ring of the transforms (ntt_core_f64.hpp); 0 = off
+#endif
+#ifndef KX_SLOT_MAJOR
+#define KX_SLOT_MAJOR 0
+#endif
+
+struct KsArgsX {
+    const KsModF64* mods;    // [K]
+    const double* tables;    // [K][4][n]: w, w/p, inverse w (first entry at index 1), inverse w/p
+    const double* keys;      // [L][L+1][2][n] centred, B order of THIS geometry
+    double* c;               // [chunk][L][n]   canonical, natural order
+    double* s;               // [chunk][2][n]   canonical, natural order
+    const u64* t_target;     // [chunk][L][n]
+    u64* result;             // [chunk][2][L][n]
+    u32 L, K, nb;
+    unsigned long long* stamps;   // tools/ksx_timeline.hip only (KX_TIMELINE builds): [workgroup][wave][KX_NST]
+};
+
+// Optional per-wave cycle stamps at the phase boundaries of a round (tools/ksx_timeline.hip). No waits are forced:
+// a stamp shows when the wave's instruction stream got there.
+#ifdef KX_TIMELINE
+constexpr int KX_NST = 64;
+#define KX_STAMP(i)                                                                                            \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int r_ = 0; r_ < G::E; ++r_) asm volatile("" : "+v"(v[r_]));                    \
+        if (a.stamps && (threadIdx.x & 63) == 0)                                                               \
+            a.stamps[(size_t(blockIdx.x) * (G::T / 64) + (threadIdx.x >> 6)) * KX_NST + (i)] = __builtin_readcyclecounter(); \
+        _Pragma("unroll") for (int r_ = 0; r_ < G::E; ++r_) asm volatile("" : "+v"(v[r_]));                    \
+    } while (0)
+#else
+#define KX_STAMP(i) do { } while (0)
+#endif
+
+// Workgroups of one XCD that stream the SAME key rows in lockstep (all of k_ksx_special; the same-limb workgroups of
+// k_ksx_main) queue on the one L2 channel that holds the row: the special kernel's multiply-accumulate measured 42 k
+// cycles against 10 k for the same code on distinct rows. A start-up delay proportional to the workgroup's position
+// inside its XCD (KX_STAGGER x 64 cycles per position, 32 positions) puts them a few rows apart for good.
+#ifndef KX_STAGGER
+#define KX_STAGGER 5
+#endif
+__device__ __forceinline__ void xcd_stagger() {
+    if (KX_STAGGER > 0) {
+        const u32 pos = (blockIdx.x >> 3) & 31;
+        for (u32 i = 0; i < pos; ++i) __builtin_amdgcn_s_sleep(KX_STAGGER);
+    }
+}
+
+__device__ __forceinline__ u32 xcd_item_x(u32 bid, u32 total) {   // XCD-contiguous work ranges (keyswitch.hip)
+    const u32 q = total >> 3, r = total & 7, xcd = bid & 7, j = bid >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+// natural-order words -> centred doubles in B register order. With at most four adjacent words per lane (16
+// coefficients per thread) the loads go straight to the B positions, as in k_ksf_up; with sixteen (32 per thread) a
+// wave instruction would touch 64 cache lines, so the loads are A order (a wave reads 512 contiguous bytes per
+// register) and the A -> B exchange is a cross-wave re-deal through LDS.
+template <class G>
+__device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* __restrict__ src, double* lds, int tid,
+                                                  const Mod m) {
+    if constexpr (G::KL <= 2) {
+        const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64((src + G::idxB(r, 0))[tB]), m);
+    } else {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64((src + G::idxA(r, 0))[u32(tid)]), m);
+        redeal_x<G, false, true>(v, lds, tid, [](int r, int t) { return G::idxA(r, t); },
+                                 [](int r, int t) { return G::idxB(r, t); });
+    }
+}
+
+// acc_k += v . key_k for the thread's E coefficients, bringing the accumulators back to |x| <= p/2 + 2 every term.
+// LAZY bounds (f64_arith.hpp): |v| <= 2.14p, |key| <= p/2  =>  |v.key mod p| <= 1.31p by mul_mod, so
+// |acc + product| <= 1.81p; strict kernels (moduli up to 2^52, |v| <= p/2 + 2): 0.5p + 0.7p < 2p.
+// (Reducing only every second term under a wave-uniform branch costs more than it saves: the two copies of the
+// accumulators meet in 128 phi nodes and the allocator spills ~200 registers.)
+// The keys stream through a ring of PF register pairs requested PF coefficients ahead; as soon as v[r] is consumed
+// its register receives word r of the NEXT round's input (`next`, A order; never null), so that input crosses
+// the memory system during this multiply-accumulate instead of stalling the next transform. A scheduling barrier per
+// coefficient keeps the compiler from hoisting the whole stream to the top (and spilling what it displaced).
+// position of register r / thread tid in a natural-order array about to enter an INVERSE transform (B order): direct
+// for small lane runs, A order (then re-dealt through LDS) otherwise -- see load_natural_to_B
+template <class G>
+__device__ __forceinline__ int in_pos(int r, int tid) { return G::KL <= 2 ? G::idxB(r, tid) : G::idxA(r, tid); }
+
+template <class G, bool NEXT_B = false, int PF = 6>
+__device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
+                                         const double* __restrict__ k0, const double* __restrict__ k1,
+                                         const double* __restrict__ next, int tid, const Mod m) {
+    double ka[PF], kb[PF];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) { ka[r] = (k0 + r * G::T)[u32(tid)]; kb[r] = (k1 + r * G::T)[u32(tid)]; }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const double a = ka[r % PF], b = kb[r % PF];
+        if (r + PF < G::E) { ka[r % PF] = (k0 + (r + PF) * G::T)[u32(tid)]; kb[r % PF] = (k1 + (r + PF) * G::T)[u32(tid)]; }
+        const double x = v[r];
+#if KX_NEXT_MODE == 0
+        v[r] = NEXT_B ? (next + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))] : (next + G::idxA(r, 0))[u32(tid)];
+#endif
+        acc0[r] = hxf::reduce(acc0[r] + hxf::mul_mod(x, a, m), m);
+        acc1[r] = hxf::reduce(acc1[r] + hxf::mul_mod(x, b, m), m);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#if KX_NEXT_MODE == 1
+    // the next input is requested in ONE burst behind the last key: vector memory returns in order, so a slow (HBM)
+    // request between two key requests delays every key behind it
+#pragma unroll
+    for (int r = 0; r < G::E; ++r)
+        v[r] = NEXT_B ? (next + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))] : (next + G::idxA(r, 0))[u32(tid)];
+#endif
+}
+
+// Both kernels are ONE loop around ONE inlined instance of each transform they need: at 32 coefficients per thread a
+// transform is ~20 KB of straight-line code, and the two CUs that share a 64 KB instruction cache must hold the whole
+// loop body (a first version with a transform instance per phase -- 65-76 KB per kernel -- ran at half the speed).
+
+// ---- special slot: steps 1-4 for one instance -------------------------------------------------------------------
+// step 4 for one k: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2) (mod q_sp), canonical   (intt2_redu.hpp:25,43)
+template <class G, class W>
+__device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __restrict__ dst, double* lds, int tid,
+                                                 const double* ts, const KsModF64& msp) {
+    W::template inverse<false>(v, lds, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r)
+        (dst + G::idxA(r, 0))[u32(tid)] = hxf::lift(hxf::reduce(hxf::lift(v[r], msp.m) + msp.half, msp.m), msp.m);
+}
+
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
+    extern __shared__ __attribute__((aligned(16))) double ldsx[];
+    const u32 L = a.L;
+    const u32 b = blockIdx.x;
+    const u32 isp = a.K - 1;
+    const KsModF64 msp = a.mods[isp];
+    double acc0[G::E], acc1[G::E];
+    double v[G::E];                                               // raw words of the round's input between rounds
+    xcd_stagger();
+    {
+        const int tid = threadIdx.x;
+        const double* t0 = reinterpret_cast<const double*>(a.t_target + size_t(b) * L * G::N);
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = (t0 + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))]; }
+    }
+    // rounds d = 0..L-1: c_d = INTT(t_target[d]), acc += NTT_sp(c_d) . key[d][special]
+#pragma unroll 1
+    for (u32 it = 0; it < L; ++it) {
+        int tid = threadIdx.x;                                    // laundered per round (see k_ksf_up)
+        asm volatile("" : "+v"(tid));
+        u32 toff = it * 4 * G::N, tsp = isp * 4 * G::N;
+        asm volatile("" : "+s"(toff), "+s"(tsp));
+        const KsModF64 md = a.mods[it];
+        const double* tb = a.tables + toff;
+        KX_STAMP(4 * it + 0);
+        // natural-order words -> centred doubles in B order
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64((u64)__double_as_longlong(v[r])), md.m);
+        if constexpr (G::KL > 2)                                  // requested in A order: A -> B through LDS
+            redeal_x<G, false, true>(v, ldsx, tid, [](int r, int t) { return G::idxA(r, t); },
+                                     [](int r, int t) { return G::idxB(r, t); });
+        KX_STAMP(4 * it + 1);
+        W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+        KX_STAMP(4 * it + 2);
+        double* cd = a.c + (size_t(b) * L + it) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            v[r] = hxf::lift(v[r], md.m);                         // canonical c_d, A order
+            (cd + G::idxA(r, 0))[u32(tid)] = v[r];
+        }
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], msp.m);                 // intt1_redu.hpp:36-42
+        const double* ts = a.tables + tsp;
+        W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
+        KX_STAMP(4 * it + 3);
+        const double* k0 = a.keys + ((size_t(it) * (L + 1) + L) * 2) * G::N;
+        // the next round's t_target limb streams in behind the products (the last one is requested twice: harmless)
+        const u32 nd = it + 1 < L ? it + 1 : it;
+        const double* nxt = reinterpret_cast<const double*>(a.t_target + (size_t(b) * L + nd) * G::N);
+        mac_keys<G, true>(acc0, acc1, v, k0, k0 + G::N, nxt, tid, msp.m);
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 tsp = isp * 4 * G::N;
+        asm volatile("" : "+s"(tsp));
+        KX_STAMP(4 * L + 0);
+        ksx_special_down<G, W>(acc0, a.s + (size_t(b) * 2 + 0) * G::N, ldsx, tid, a.tables + tsp, msp);
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 tsp = isp * 4 * G::N;
+        asm volatile("" : "+s"(tsp));
+        KX_STAMP(4 * L + 4);
+        ksx_special_down<G, W>(acc1, a.s + (size_t(b) * 2 + 1) * G::N, ldsx, tid, a.tables + tsp, msp);
+        KX_STAMP(4 * L + 8);
+    }
+}
+
+// ---- decomposition slots: steps 2-3 and 5-7 for one (instance, limb) ----------------------------------------------
+// steps 5-7 for one k: w = NTT((s'_k + fix_i) mod q_i) from the raw s'_k words in v (A order); result[k][i] += (acc - w) * msf_i
+template <class G, class W>
+__device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
+                                               double* lds, int tid, const double* tb, const KsModF64& md) {
+    const Mod m = md.m;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r] + md.fix, m);             // intt2_redu.hpp:49-51
+    W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);               // |w| <= 2.14p: |prod - w| <= 2.64p
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
+    if constexpr (G::KL <= 2) {
+        // read-modify-write at the B positions, half of the registers at a time (a full register copy of the old words
+        // does not fit beside the accumulators)
+        const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+        for (int r0 = 0; r0 < G::E; r0 += G::E / 2) {
+            u64 old[G::E / 2];
+#pragma unroll
+            for (int r = 0; r < G::E / 2; ++r) old[r] = (res + G::idxB(r0 + r, 0))[tB];
+#pragma unroll
+            for (int r = 0; r < G::E / 2; ++r) {
+                const double rr = hxf::reduce(hxf::to_f64(old[r]) + v[r0 + r], m);               // fpga.cpp:453-457
+                (res + G::idxB(r0 + r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    // result is natural order, v is B order: the old words go through LDS (written at their A positions, read and
+    // replaced by the sums at the thread's own B positions, read back at the A positions), eight loads in flight at a
+    // time -- a register copy of them would not fit beside the accumulators
+    double* const atA = lds + G::pad(G::idxA(0, tid));
+    double* const atB = lds + G::pad(G::idxB(0, tid));
+    __syncthreads();                                              // other waves may still read the last re-deal
+#pragma unroll
+    for (int r0 = 0; r0 < G::E; r0 += 8) {
+#pragma unroll
+        for (int r = r0; r < r0 + 8; ++r)
+            atA[G::pad(G::idxA(r, 0))] = hxf::reduce(hxf::to_f64((res + G::idxA(r, 0))[u32(tid)]), m);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const double o = atB[G::pad(G::idxB(r, 0))];
+        atB[G::pad(G::idxB(r, 0))] = hxf::lift(hxf::reduce(o + v[r], m), m);         // fpga.cpp:453-457
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) (res + G::idxA(r, 0))[u32(tid)] = hxf::from_f64(atA[G::pad(G::idxA(r, 0))]);
+}
+
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
+    extern __shared__ __attribute__((aligned(16))) double ldsx[];
+    const u32 L = a.L;
+    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));
+#if KX_SLOT_MAJOR
+    // SLOT-major, XCD-contiguous: an XCD works on one or two limbs at a time, whose keys (2 L n words per limb) then
+    // stay in its L2; c_d and s' of one instance are fetched by up to L XCDs (the Infinity Cache absorbs that)
+    const u32 i = item / a.nb, b = item - i * a.nb;
+#else
+    // instance-major, XCD-contiguous: the L workgroups that read the same c_d and s' run side by side on one XCD
+    const u32 b = item / L, i = item - b * L;
+#endif
+    const KsModF64 md = a.mods[i];
+    const Mod m = md.m;
+    // round `it` reads c_it (it < L, skipping it == i) or s'_{it-L}
+    auto round_src = [&](u32 it) { return it < L ? a.c + (size_t(b) * L + it) * G::N : a.s + (size_t(b) * 2 + (it - L)) * G::N; };
+    const u32 first = i == 0 ? 1u : 0u;
+    double acc0[G::E], acc1[G::E];
+    double v[G::E];                                               // between rounds: the next round's input, A order
+    if (blockIdx.x < 8 * 32) xcd_stagger();                       // first generation only: later ones inherit it
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
+    {
+        // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
+        const int tid = threadIdx.x;
+        KX_STAMP(60);
+        load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
+        KX_STAMP(61);
+        const double* k0 = a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N;
+        mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, round_src(first), tid, m);
+    }
+    // rounds d != i: acc += NTT(c_d mod q_i) . key[d][i]
+#pragma unroll 1
+    for (u32 it = first; it < L;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 toff = i * 4 * G::N;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        KX_STAMP(4 * it + 0);
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);                 // intt1_redu.hpp:36-42
+        KX_STAMP(4 * it + 1);
+        W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
+        KX_STAMP(4 * it + 2);
+        u32 nit = it + 1;
+        if (nit == i) ++nit;
+        const double* k0 = a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N;
+        mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
+        it = nit;
+    }
+    // rounds L, L+1 (k = 0, 1)
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 toff = i * 4 * G::N;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        KX_STAMP(4 * L + 0);
+        ksx_down_round<G, W>(v, acc0, a.result + ((size_t(b) * 2 + 0) * L + i) * G::N, ldsx, tid, tb, md);
+        const double* nxt = a.s + (size_t(b) * 2 + 1) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
+        KX_STAMP(4 * L + 4);
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 toff = i * 4 * G::N;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        ksx_down_round<G, W>(v, acc1, a.result + ((size_t(b) * 2 + 1) * L + i) * G::N, ldsx, tid, tb, md);
+        KX_STAMP(4 * L + 8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class K>
+static int set_lds_x(K kern, size_t bytes) {
+    HX_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <int LOGN, int LOGE, int LAZY>
+static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
+    using G = Geom<LOGN, LOGE>;
+    static PerDeviceOnce once;
+    if (int rc0 = once.run(p->ctx->device, [] {
+            int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY>, G::LDS_USED);
+            return rc;
+        }))
+        return rc0;
+    hipStream_t st = p->cur;
+    // timing stages: 1 = special slot (steps 1-4), 2 = nothing, 4 = decomposition slots (steps 2-3, 5-7)
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1)
+        hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY>), dim3(a.nb), dim3(G::T), G::LDS_USED, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
+    if (stage_mask & 4)
+        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[3], st));
+    return (int)hipGetLastError();
+}
+
+size_t hx_ks_x_scratch_words(size_t L) { return L + 2; }   // per instance, in units of n (fits the (b, d)-major scratch)
+
+// Large chunks of N = 16384 instances: one workgroup per (instance, limb) must fill the chip at least twice, like the
+// fused k_ksf_up of the (b, d)-major pipeline. HEXL_KS_PIPE=1 keeps the (b, d)-major pipeline (tests, comparisons).
+u32 hx_ks_x_loge() {                                              // HEXL_KSX_LOGE=5: 32 coefficients x 512 threads
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("HEXL_KSX_LOGE"); v = (e && atoi(e) == 5) ? 5 : 4; }
+    return (u32)v;
+}
+bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
+    static int pipe = -1;
+    if (pipe < 0) { const char* e = getenv("HEXL_KS_PIPE"); pipe = e ? atoi(e) : 2; }
+    if (!p->d_keys_x || p->logn != 14) return false;
+    return pipe == 3 || (pipe == 2 && nb * p->L >= 2 * (size_t)p->ctx->num_cu);      // 3: always (tests)
+}
+
+int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
+                          hipEvent_t* ev) {
+    const size_t n = p->n, L = p->L;
+    KsArgsX a;
+    a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_x;
+    a.c = (double*)p->cur_scratch;
+    a.s = a.c + p->cap * L * n;
+    a.t_target = d_t_target; a.result = d_result;
+    a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    a.stamps = nullptr;
+    if (p->logn != 14) return HEXL_E_BADARG;
+    if (p->x_loge == 4) return p->f64_lazy ? run_chunk_x<14, 4, 3>(p, a, stage_mask, ev) : run_chunk_x<14, 4, 0>(p, a, stage_mask, ev);
+    if (p->f64_lazy) return run_chunk_x<14, 5, 3>(p, a, stage_mask, ev);
+    return run_chunk_x<14, 5, 0>(p, a, stage_mask, ev);
+}

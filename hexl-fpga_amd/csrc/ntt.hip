@@ -222,12 +222,12 @@ u32 hx_idxB(u32 logn, u32 r, u32 tid) {
 template <int LOGN, int LOGE>
 static int launch_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q) {
     using G = Geom<LOGN, LOGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd<LOGN, LOGE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = once.run(ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+            return 0;
+        }))
+        return rc;
     hipLaunchKernelGGL((k_ntt_fwd<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, (u32)batch);
     return (int)hipGetLastError();
@@ -237,12 +237,12 @@ template <int LOGN, int LOGE>
 static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const u64* ip, u64 q, u64 a, u64 ap,
                       u64 b, u64 bp) {
     using G = Geom<LOGN, LOGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv<LOGN, LOGE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = once.run(ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+            return 0;
+        }))
+        return rc;
     hipLaunchKernelGGL((k_ntt_inv<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x, ir,
                        ip, q, a, ap, b, bp, (u32)batch);
     return (int)hipGetLastError();
@@ -252,12 +252,12 @@ template <int LOGN, int LOGE, int LAZY>
 static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q,
                         const double* w, const double* wp, const u32* viol) {
     using G = Geom<LOGN, LOGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_x<LOGN, LOGE, LAZY>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = once.run(ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_x<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+            return 0;
+        }))
+        return rc;
     hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, w, wp, viol, (u32)batch);
     return (int)hipGetLastError();
@@ -267,12 +267,12 @@ template <int LOGN, int LOGE, int LAZY>
 static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const u64* ip, u64 q, u64 a, u64 ap, u64 b,
                         u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* viol) {
     using G = Geom<LOGN, LOGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_x<LOGN, LOGE, LAZY>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = once.run(ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_x<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+            return 0;
+        }))
+        return rc;
     hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
     return (int)hipGetLastError();

@@ -20,29 +20,47 @@ typedef const __attribute__((address_space(4))) double* ctw_t;
 // LAZY = forward reduction period (0: strict; 3, 6 or 12 by modulus size, f64_arith.hpp): butterflies skip the range reduction except after every LAZY-th
 // global stage and after the last one (bounds in f64_arith.hpp). LOGN is only needed to find the last stage.
 // UNI: the twiddle index is wave-uniform (scalar loads through the constant address space)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false>
+// TF > 0 (register-tight kernels, keyswitch_x.hip): per-lane twiddles of a stage with more than TF of them stream
+// through a ring of TF registers, requested TF sub-blocks ahead, with a scheduling barrier every TF sub-blocks. Left
+// alone the compiler requests all 2^u twiddles of a stage (all 31 of a five-stage pass) up front: ~60 registers that
+// a kernel holding 128 accumulator registers does not have (it spilled a quarter of the accumulators for good).
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
         const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
+        constexpr int TFR = TF > 0 ? TF : 1;
+        const bool ring = TF > 0 && !UNI && (1 << u) > TF;
+        double Wq[TFR];
+        if (ring) {
+#pragma unroll
+            for (int j = 0; j < TFR; ++j) Wq[j] = w[base + j];
+        }
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
-            const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
+            double W;
+            if (ring) {
+                W = Wq[j % TFR];
+                if (j + TFR < (1 << u)) Wq[j % TFR] = w[base + j + TFR];
+            } else {
+                W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
+            }
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
                 if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
                 else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
             }
+            if (ring && (j % TFR) == TFR - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 using hxf::InvScale;
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, int TF = 0>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -50,10 +68,22 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
     for (int u = 0; u < K; ++u) {
         const bool fused = LAST && (u == K - 1);
         const u32 base = N - (N >> (LO + u)) + 1 + (G << (K - 1 - u));
+        constexpr int TFR = TF > 0 ? TF : 1;
+        const bool ring = TF > 0 && !UNI && !fused && (1 << (K - 1 - u)) > TF;       // see fwd_stages_f64
+        double Wq[TFR], Wpq[TFR];
+        if (ring) {
+#pragma unroll
+            for (int j = 0; j < TFR; ++j) { Wq[j] = iw[base + j]; Wpq[j] = iwp[base + j]; }
+        }
 #pragma unroll
         for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
             double W = 0, Wp = 0;
-            if (!fused) { W = UNI ? ((ctw_t)iw)[base + j] : iw[base + j]; Wp = UNI ? ((ctw_t)iwp)[base + j] : iwp[base + j]; }
+            if (ring) {
+                W = Wq[j % TFR]; Wp = Wpq[j % TFR];
+                if (j + TFR < (1 << (K - 1 - u))) { Wq[j % TFR] = iw[base + j + TFR]; Wpq[j % TFR] = iwp[base + j + TFR]; }
+            } else if (!fused) {
+                W = UNI ? ((ctw_t)iw)[base + j] : iw[base + j]; Wp = UNI ? ((ctw_t)iwp)[base + j] : iwp[base + j];
+            }
 #pragma unroll
             for (int c = 0; c < (1 << u); ++c) {
                 const int a0 = OFF + (j << (u + 1)) + c;
@@ -67,6 +97,7 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
                     v[a1] = hxf::reduce(hxf::mul_shoup(d, sc.nw, sc.nw_p, m), m);
                 }
             }
+            if (ring && (j % TFR) == TFR - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -81,7 +112,7 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
     __syncthreads();
 }
 
-template <int LOGN, int LOGE, int LAZY = 0>
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0>
 struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -100,7 +131,7 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6)>(v, Gp, w, wp, m);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             redeal_pass<G, LO, LOGE, true, LEAD, (PASS + 1 == G::P - 1)>(v, lds, tid);
             if constexpr (PASS == 0) after_cross();
@@ -115,7 +146,7 @@ struct WgNttF64 {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
             // LOGN = 0 tells the stage loop that no stage is the last one
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY>(v, Gbits, w, wp, m);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }
@@ -153,7 +184,7 @@ struct WgNttF64 {
                                                      const Mod m, const InvScale sc) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
-            inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY>(v, Gbits, iw, iwp, m, sc);
+            inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, false, TF>(v, Gbits, iw, iwp, m, sc);
             inv_first<GRP + 1>(v, tid, iw, iwp, m, sc);
         }
     }
@@ -165,7 +196,7 @@ struct WgNttF64 {
             constexpr bool LEAD = !(FRESH && PASS == 0);
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6)>(v, Gp, iw, iwp, m, sc);
+            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc);
         }
     }
