@@ -65,18 +65,17 @@ constexpr int KX_NST = 64;
 #define KX_STAMP(i) do { } while (0)
 #endif
 
-// Workgroups of one XCD that stream the SAME key rows in lockstep (all of k_ksx_special; the same-limb workgroups of
-// k_ksx_main) queue on the one L2 channel that holds the row: the special kernel's multiply-accumulate measured 42 k
-// cycles against 10 k for the same code on distinct rows. A start-up delay proportional to the workgroup's position
-// inside its XCD (KX_STAGGER x 64 cycles per position, 32 positions) puts them a few rows apart for good.
-#ifndef KX_STAGGER
-#define KX_STAGGER 5
-#endif
-__device__ __forceinline__ void xcd_stagger() {
-    if (KX_STAGGER > 0) {
-        const u32 pos = (blockIdx.x >> 3) & 31;
-        for (u32 i = 0; i < pos; ++i) __builtin_amdgcn_s_sleep(KX_STAGGER);
-    }
+// Persistent workgroups: the grid is 8 x g workgroups (g per XCD, normally one per CU); the g workgroups of XCD x
+// (block index & 7, MI355X_MICROARCH.md) walk that XCD's contiguous share of the item list side by side, so that items
+// which read the same intermediate run at the same time on the same L2. A workgroup that stays on its CU does not pay
+// the dispatch gap between workgroups (LDS and all 512 registers per SIMD lane are only handed over when the LAST wave
+// of the previous workgroup has finished: ~20 k cycles of a 360 k-cycle item), and its early waves already request
+// the next item's first input.
+struct XcdWalk { u32 pos, end, step; };
+__device__ __forceinline__ XcdWalk xcd_walk(u32 total) {
+    const u32 g = gridDim.x >> 3, q = total >> 3, r = total & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const u32 start = x * q + (x < r ? x : r);
+    return XcdWalk{start + j, start + q + (x < r ? 1u : 0u), g};
 }
 
 __device__ __forceinline__ u32 xcd_item_x(u32 bid, u32 total) {   // XCD-contiguous work ranges (keyswitch.hip)
@@ -160,59 +159,72 @@ __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __re
         (dst + G::idxA(r, 0))[u32(tid)] = hxf::lift(hxf::reduce(hxf::lift(v[r], msp.m) + msp.half, msp.m), msp.m);
 }
 
+// step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles in natural order, one workgroup per (instance, limb).
+// (Kept out of k_ksx_special: an inverse transform beside the 64 accumulator registers made the allocator spill a few
+// accumulators, and every reload inside the multiply-accumulate waits for the whole key prefetch queue -- vector
+// memory returns in order. That version spent 42 k cycles per multiply-accumulate instead of 10 k.)
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0>;
+    extern __shared__ __attribute__((aligned(16))) double ldsx[];
+    const XcdWalk wk = xcd_walk(a.nb * a.L);
+#pragma unroll 1
+    for (u32 item = wk.pos; item < wk.end; item += wk.step) {     // item = b*L + d
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u32 d = __builtin_amdgcn_readfirstlane(item % a.L);
+        const KsModF64 md = a.mods[d];
+        u32 toff = d * 4 * G::N;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        double v[G::E];
+        load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m);
+        W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+        double* cd = a.c + size_t(item) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) (cd + G::idxA(r, 0))[u32(tid)] = hxf::lift(v[r], md.m);
+    }
+}
+
+// steps 2-4 for the special slot of one instance: acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k], then
+// s'_k = INTT_{q_sp}(acc_k) + floor(q_sp/2)
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
-    const u32 b = blockIdx.x;
     const u32 isp = a.K - 1;
     const KsModF64 msp = a.mods[isp];
+    const XcdWalk wk = xcd_walk(a.nb);
+#pragma unroll 1
+    for (u32 b = wk.pos; b < wk.end; b += wk.step) {
     double acc0[G::E], acc1[G::E];
-    double v[G::E];                                               // raw words of the round's input between rounds
-    xcd_stagger();
+    double v[G::E];                                               // between rounds: the next round's input, A order
     {
-        const int tid = threadIdx.x;
-        const double* t0 = reinterpret_cast<const double*>(a.t_target + size_t(b) * L * G::N);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const double* c0 = a.c + size_t(b) * L * G::N;
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = (t0 + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))]; }
+        for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = (c0 + G::idxA(r, 0))[u32(tid)]; }
     }
-    // rounds d = 0..L-1: c_d = INTT(t_target[d]), acc += NTT_sp(c_d) . key[d][special]
 #pragma unroll 1
     for (u32 it = 0; it < L; ++it) {
         int tid = threadIdx.x;                                    // laundered per round (see k_ksf_up)
         asm volatile("" : "+v"(tid));
-        u32 toff = it * 4 * G::N, tsp = isp * 4 * G::N;
-        asm volatile("" : "+s"(toff), "+s"(tsp));
-        const KsModF64 md = a.mods[it];
-        const double* tb = a.tables + toff;
+        u32 tsp = isp * 4 * G::N;
+        asm volatile("" : "+s"(tsp));
+        const double* ts = a.tables + tsp;
         KX_STAMP(4 * it + 0);
-        // natural-order words -> centred doubles in B order
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64((u64)__double_as_longlong(v[r])), md.m);
-        if constexpr (G::KL > 2)                                  // requested in A order: A -> B through LDS
-            redeal_x<G, false, true>(v, ldsx, tid, [](int r, int t) { return G::idxA(r, t); },
-                                     [](int r, int t) { return G::idxB(r, t); });
-        KX_STAMP(4 * it + 1);
-        W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
-        KX_STAMP(4 * it + 2);
-        double* cd = a.c + (size_t(b) * L + it) * G::N;
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) {
-            v[r] = hxf::lift(v[r], md.m);                         // canonical c_d, A order
-            (cd + G::idxA(r, 0))[u32(tid)] = v[r];
-        }
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], msp.m);                 // intt1_redu.hpp:36-42
-        const double* ts = a.tables + tsp;
+        KX_STAMP(4 * it + 1);
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
-        KX_STAMP(4 * it + 3);
+        KX_STAMP(4 * it + 2);
         const double* k0 = a.keys + ((size_t(it) * (L + 1) + L) * 2) * G::N;
-        // the next round's t_target limb streams in behind the products (the last one is requested twice: harmless)
-        const u32 nd = it + 1 < L ? it + 1 : it;
-        const double* nxt = reinterpret_cast<const double*>(a.t_target + (size_t(b) * L + nd) * G::N);
-        mac_keys<G, true>(acc0, acc1, v, k0, k0 + G::N, nxt, tid, msp.m);
+        const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
+        mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
     }
     {
         int tid = threadIdx.x;
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
         KX_STAMP(4 * L + 4);
         ksx_special_down<G, W>(acc1, a.s + (size_t(b) * 2 + 1) * G::N, ldsx, tid, a.tables + tsp, msp);
         KX_STAMP(4 * L + 8);
+    }
     }
 }
 
@@ -292,7 +305,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
     using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
+    // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler
+    // hoists out of the item loop costs more registers (34 spilled against 10) than the dispatch gaps cost time
     const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));
+    {
 #if KX_SLOT_MAJOR
     // SLOT-major, XCD-contiguous: an XCD works on one or two limbs at a time, whose keys (2 L n words per limb) then
     // stay in its L2; c_d and s' of one instance are fetched by up to L XCDs (the Infinity Cache absorbs that)
@@ -308,12 +324,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
     const u32 first = i == 0 ? 1u : 0u;
     double acc0[G::E], acc1[G::E];
     double v[G::E];                                               // between rounds: the next round's input, A order
-    if (blockIdx.x < 8 * 32) xcd_stagger();                       // first generation only: later ones inherit it
 #pragma unroll
     for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
     {
         // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
-        const int tid = threadIdx.x;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         KX_STAMP(60);
         load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
         KX_STAMP(61);
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
         ksx_down_round<G, W>(v, acc1, a.result + ((size_t(b) * 2 + 1) * L + i) * G::N, ldsx, tid, tb, md);
         KX_STAMP(4 * L + 8);
     }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,16 +395,27 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
             int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksx_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY>, G::LDS_USED);
             return rc;
         }))
         return rc0;
     hipStream_t st = p->cur;
-    // timing stages: 1 = special slot (steps 1-4), 2 = nothing, 4 = decomposition slots (steps 2-3, 5-7)
+    // timing stages: 1 = step 1 (inverse transforms), 2 = special slot (steps 2-4), 4 = decomposition slots (steps 2-3, 5-7)
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    // persistent grids: 8 x g workgroups, g = workgroups per XCD = one per CU unless there are fewer items
+    // (HEXL_KSX_PERSIST=0: one workgroup per item)
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("HEXL_KSX_PERSIST"); persist = e ? atoi(e) : 1; }
+    auto grid_for = [&](u32 items) {
+        const u32 per_xcd = (items + 7) / 8, cu_per_xcd = ((u32)p->ctx->num_cu + 7) / 8;
+        return dim3(8 * (persist && per_xcd > cu_per_xcd ? cu_per_xcd : per_xcd));
+    };
     if (stage_mask & 1)
-        hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY>), dim3(a.nb), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY>), grid_for(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (stage_mask & 2)
+        hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
         hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
@@ -422,7 +450,13 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.stamps = nullptr;
     if (p->logn != 14) return HEXL_E_BADARG;
-    if (p->x_loge == 4) return p->f64_lazy ? run_chunk_x<14, 4, 3>(p, a, stage_mask, ev) : run_chunk_x<14, 4, 0>(p, a, stage_mask, ev);
-    if (p->f64_lazy) return run_chunk_x<14, 5, 3>(p, a, stage_mask, ev);
-    return run_chunk_x<14, 5, 0>(p, a, stage_mask, ev);
+    // LAZY template argument = forward reduction period of the transforms (f64_arith.hpp), as in keyswitch_f64.hip
+    if (p->x_loge == 5)                                           // 32 coefficients x 512 threads: measured slower, kept for study
+        return p->f64_lazy ? run_chunk_x<14, 5, 3>(p, a, stage_mask, ev) : run_chunk_x<14, 5, 0>(p, a, stage_mask, ev);
+    switch (p->f64_lazy) {
+        case 12: return run_chunk_x<14, 4, 12>(p, a, stage_mask, ev);
+        case 6:  return run_chunk_x<14, 4, 6>(p, a, stage_mask, ev);
+        case 3:  return run_chunk_x<14, 4, 3>(p, a, stage_mask, ev);
+        default: return run_chunk_x<14, 4, 0>(p, a, stage_mask, ev);
+    }
 }

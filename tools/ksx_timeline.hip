@@ -56,15 +56,24 @@ int main(int argc, char** argv) {
     hipMemcpy(dres, res.data(), res.size() * 8, hipMemcpyHostToDevice);
     a.mods = dm; a.tables = dt; a.keys = dk; a.c = dc; a.s = ds; a.t_target = dtt; a.result = dres;
     a.L = L; a.K = K; a.nb = nb; a.stamps = dst;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto kin = k_ksx_intt<14, KX_LOGE, 3>;
+    hipFuncSetAttribute((const void*)kin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kin, dim3((nb * L + 7) / 8 * 8), dim3(G::T), G::LDS_USED, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep) printf("==== k_ksx_intt: grid %u, %.1f us = %.1f us per round of 256 workgroups\n", nb * L, ms * 1e3, ms * 1e3 / ((nb * L + 255) / 256));
+    }
     auto ksp = k_ksx_special<14, KX_LOGE, 3>;
     auto kmn = k_ksx_main<14, KX_LOGE, 3>;
     hipFuncSetAttribute((const void*)ksp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
     hipFuncSetAttribute((const void*)kmn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int W = G::T / 64;
     std::vector<unsigned long long> s(nst);
     for (int which = 0; which < 2; ++which) {
-        const u32 grid = which ? nb * L : nb;
+        const u32 grid = ((which ? nb * L : nb) + 7) / 8 * 8;   // one item per workgroup: stamps stay per item
         float ms = 0;
         for (int rep = 0; rep < 2; ++rep) {
             hipMemset(dst, 0, nst * 8);
@@ -100,7 +109,7 @@ int main(int argc, char** argv) {
             span += double(t1 - t0); skew += double(t1 - emin);
         }
         if (which) printf("  diagonal: load t_i -> B %8.0f cycles, multiply-accumulate (+ first input request) %8.0f cycles\n", diag_ld / nd, diag_mac / nd);
-        const char* nm_sp[4] = {"input convert + A->B re-deal", "inverse transform", "lift/store c + reduce + forward (up) | store s' (last)", "multiply-accumulate"};
+        const char* nm_sp[4] = {"wait for input + reduce | inverse + store s' (last two)", "forward transform", "multiply-accumulate", ""};
         const char* nm_mn[4] = {"wait for input + reduce", "forward transform", "multiply-accumulate (up) | result epilogue (down)", ""};
         for (int r = 0; r < rounds; ++r)
             for (int k = 0; k < 4; ++k)
