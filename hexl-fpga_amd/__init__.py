@@ -34,6 +34,7 @@ _i = ctypes.c_int
 # symbol -> argtypes; every function returns int status. Mirrors include/hexl_mi355x.h 1:1
 # (tests/test_abi.py checks the header and this table against the built library).
 C_ABI = {
+    "hexl_device_count": [],
     "hexl_ctx_create": [_i, ctypes.POINTER(_vp)],
     "hexl_ctx_destroy": [_vp],
     "hexl_ctx_set_stream": [_vp, _vp],

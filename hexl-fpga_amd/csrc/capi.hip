@@ -24,6 +24,12 @@ int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need) {
     return 0;
 }
 
+extern "C" int hexl_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count;
+}
+
 extern "C" int hexl_ctx_create(int device, hexl_ctx** out) {
     if (!out) return HEXL_E_BADARG;
     int count = 0;
@@ -353,13 +359,12 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 #include <condition_variable>
 #include <memory>
 
-static unsigned host_threads() {
-    static unsigned n = 0;
-    if (!n) {
+static unsigned host_threads() {                                   // (thread-safe static: several device runners call this)
+    static const unsigned n = [] {
         const char* e = getenv("HEXL_HOST_THREADS");
-        n = e ? (unsigned)atoi(e) : std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
-        if (!n) n = 1;
-    }
+        const unsigned v = e ? (unsigned)atoi(e) : std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        return v ? v : 1u;
+    }();
     return n;
 }
 

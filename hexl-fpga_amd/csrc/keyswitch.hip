@@ -193,12 +193,11 @@ static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_
 }
 
 static size_t ks_chunk_default() {
-    static long v = -1;
-    if (v < 0) {
+    static const long v = [] {
         const char* e = getenv("HEXL_KS_CHUNK");
-        v = e ? atol(e) : 256;
-        if (v < 1) v = 1;
-    }
+        const long c = e ? atol(e) : 256;
+        return c < 1 ? 1L : c;
+    }();
     return (size_t)v;
 }
 

@@ -289,8 +289,7 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     const u32 cus = (u32)p->ctx->num_cu;
     // (the same fusion of steps 4-7 -- s' in registers, L mod-down transforms per workgroup -- measured 8 % slower
     // than the two kernels below: its epilogue loads cannot be requested early, tools/experiments/fused_down.patch)
-    static int fuse = -1;
-    if (fuse < 0) { const char* e = getenv("HEXL_KS_FUSE"); fuse = e ? atoi(e) : 1; }
+    static const int fuse = [] { const char* e = getenv("HEXL_KS_FUSE"); return e ? atoi(e) : 1; }();
     const bool fused_up = (fuse & 1) && nb * L >= 2 * cus && !G::HALF_ONLY;   // N = 32768: 64 VGPRs of data already
     // timing stages: 1 = steps 1-2 (inverse + mod-up transforms), 2 = steps 3-4, 4 = steps 5-7
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));

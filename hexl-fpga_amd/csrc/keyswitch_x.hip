@@ -405,8 +405,7 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     // persistent grids: 8 x g workgroups, g = workgroups per XCD = one per CU unless there are fewer items
     // (HEXL_KSX_PERSIST=0: one workgroup per item)
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("HEXL_KSX_PERSIST"); persist = e ? atoi(e) : 1; }
+    static const int persist = [] { const char* e = getenv("HEXL_KSX_PERSIST"); return e ? atoi(e) : 1; }();
     auto grid_for = [&](u32 items) {
         const u32 per_xcd = (items + 7) / 8, cu_per_xcd = ((u32)p->ctx->num_cu + 7) / 8;
         return dim3(8 * (persist && per_xcd > cu_per_xcd ? cu_per_xcd : per_xcd));
@@ -428,13 +427,11 @@ size_t hx_ks_x_scratch_words(size_t L) { return L + 2; }   // per instance, in u
 // Large chunks of N = 16384 instances: one workgroup per (instance, limb) must fill the chip at least twice, like the
 // fused k_ksf_up of the (b, d)-major pipeline. HEXL_KS_PIPE=1 keeps the (b, d)-major pipeline (tests, comparisons).
 u32 hx_ks_x_loge() {                                              // HEXL_KSX_LOGE=5: 32 coefficients x 512 threads
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("HEXL_KSX_LOGE"); v = (e && atoi(e) == 5) ? 5 : 4; }
+    static const int v = [] { const char* e = getenv("HEXL_KSX_LOGE"); return (e && atoi(e) == 5) ? 5 : 4; }();
     return (u32)v;
 }
 bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
-    static int pipe = -1;
-    if (pipe < 0) { const char* e = getenv("HEXL_KS_PIPE"); pipe = e ? atoi(e) : 2; }
+    static const int pipe = [] { const char* e = getenv("HEXL_KS_PIPE"); return e ? atoi(e) : 2; }();
     if (!p->d_keys_x || p->logn != 14) return false;
     return pipe == 3 || (pipe == 2 && nb * p->L >= 2 * (size_t)p->ctx->num_cu);      // 3: always (tests)
 }

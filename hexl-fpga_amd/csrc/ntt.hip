@@ -136,9 +136,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
 }
 
 static bool fast_path_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("HEXL_NTT_INT"); v = (e && atoi(e) == 1) ? 0 : 1; }
-    return v == 1;
+    static const bool v = [] { const char* e = getenv("HEXL_NTT_INT"); return !(e && atoi(e) == 1); }();
+    return v;
 }
 
 // device scratch for the derived tables: [w | w/p] (n doubles each) + the violation counter
@@ -201,11 +200,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv(u64* __restrict_
 }
 
 u32 hx_loge_for(u32 logn) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("HEXL_NTT_LOGE");
-        forced = e ? atoi(e) : 0;
-    }
+    static const int forced = [] { const char* e = getenv("HEXL_NTT_LOGE"); return e ? atoi(e) : 0; }();
     // N = 16384: 16 coefficients per thread x 1024 threads (4 waves/SIMD) measured ~10 % faster than 32 x 512
     if (logn == 14) return forced == 5 ? 5 : 4;
     return logn <= 10 ? 4 : 5;

@@ -4,23 +4,36 @@
 // It replaces the reference's L3/L2 host layers: host/src/hexl-fpga.cpp (forwarding),
 // host/src/{dyadic_multiply,keyswitch,ntt,intt}.cpp (argument checks), host/src/fpga_int.cpp (worksize,
 // fence and completion logic :171-507) and the Buffer / Device::run / DevicePool machinery of
-// host/src/fpga.cpp:100-180,780-866,1609-1685. Semantics kept:
-//   * one FIFO per primitive; a batch never spans a change of op parameters (fence, fpga_int.cpp:346-353,
-//     429-447) -- consecutive compatible objects are launched together;
-//   * worksize 1 => the call returns after completion; XCompleted() drains, returns true, resets ws to 1;
-//   * NUM_DEV devices each take a contiguous share of a batch (the reference: one runner thread per board
-//     popping the shared queue, fpga.cpp:1664-1672); keys/twiddles are cached per device and keyed by the
-//     k_switch_keys pointer values (fpga.cpp:1158-1165).
+// host/src/fpga.cpp:100-180,780-866,1609-1685. Same shape as the reference:
+//   * X() only appends an object to ONE submission-ordered FIFO (Buffer::push, fpga_int.cpp:420-462) and
+//     returns; with worksize 1 it then waits for that object, like fpga_int.cpp:459-461.
+//   * one RUNNER THREAD PER DEVICE (NUM_DEV, fpga.cpp:1646-1673) pops the head of the FIFO as soon as
+//     something is there -- a maximal run of consecutive objects of one primitive with the same
+//     parameters (the reference's batches never span a parameter change either: fences,
+//     fpga_int.cpp:346-353,429-447) -- and pushes it through the device's staging pipeline while the caller keeps
+//     enqueuing. Each device context is touched by its own runner only.
+//   * XCompleted() waits on a condition variable until every object of that primitive is done (the reference
+//     spins on ready_, fpga_int.cpp:484-507), returns true and resets the worksize to 1.
+//   * several devices take contiguous shares of a run. Objects whose OUTPUT array is still being produced on
+//     another device wait for it (KeySwitch accumulates into `result`; benchmark/bench_keyswitch.cpp:113-131
+//     submits the same result many times), and runs of different primitives never overlap, so the results are
+//     those of the reference's in-order queue.
+//   * keys / twiddles are cached per device and keyed by the parameter values and the k_switch_keys pointer
+//     values (fpga.cpp:1158-1165); consecutive objects are matched by pointer identity first, like
+//     fpga_int.cpp:429-447, so a steady stream of KeySwitch calls does not copy or compare parameter vectors.
 #include "../../include/hexl-fpga.h"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <thread>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hexl_mi355x.h"
@@ -38,38 +51,67 @@ unsigned long env_ul(const char* name, unsigned long dflt) {
     return e ? std::strtoul(e, nullptr, 10) : dflt;
 }
 
-struct KsKey {   // identifies a device-side plan: parameters + key pointer identity
-    uint64_t n, L, K, rns;
+enum Kind { DY = 0, KS = 1, NTT = 2, INTT = 3, NKIND = 4 };
+const char* kind_name[NKIND] = {"DyadicMultiply", "KeySwitch", "NTT", "INTT"};
+
+struct KsKey {   // identifies a device-side plan: parameter VALUES + key pointer identity + a fingerprint of the keys
+    uint64_t n, L, K, rns, fp;
     std::vector<uint64_t> moduli, msf;
     std::vector<const uint64_t*> keys;
     const uint64_t* twiddles;
     bool operator<(const KsKey& o) const {
-        return std::tie(n, L, K, rns, moduli, msf, keys, twiddles) <
-               std::tie(o.n, o.L, o.K, o.rns, o.moduli, o.msf, o.keys, o.twiddles);
+        return std::tie(n, L, K, rns, fp, moduli, msf, keys, twiddles) <
+               std::tie(o.n, o.L, o.K, o.rns, o.fp, o.moduli, o.msf, o.keys, o.twiddles);
     }
-    bool operator==(const KsKey& o) const { return !(*this < o) && !(o < *this); }
+};
+
+// The reference's device key cache is keyed by the k_switch_keys pointer alone (Device::KeySwitch_check_keys,
+// fpga.cpp:1158-1165): keys re-allocated at a recycled address with new contents silently hit the stale entry. A
+// fingerprint of a few words of every key limb (first and last four of each key component) makes that case a miss.
+uint64_t key_fingerprint(const uint64_t** keys, uint64_t L, uint64_t K, uint64_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
+    for (uint64_t d = 0; d < L; ++d) {
+        const uint64_t* k = keys[d];
+        for (uint64_t c = 0; c < 2; ++c) {
+            const uint64_t* comp = k + c * K * n;
+            for (int j = 0; j < 4; ++j) { mix(comp[j]); mix(comp[K * n - 1 - j]); }
+        }
+    }
+    return h;
+}
+
+// one queued call. `out` is the array the object writes (the aliasing rule looks at it); p0..p3 and s0..s3 are the
+// call's remaining pointers / scalars in argument order; plan = index into Engine::ks_keys for KeySwitch.
+struct Obj {
+    Kind kind;
+    uint64_t* out;
+    const uint64_t *p0, *p1, *p2;
+    uint64_t n, s0, s1, s2;
+    int plan;
 };
 
 struct Device {
     hexl_ctx* ctx = nullptr;
-    std::map<KsKey, hexl_ks_plan*> plans;
+    std::map<int, hexl_ks_plan*> plans;        // by Engine::ks_keys index; touched by this device's runner only
+    std::thread runner;
 };
-
-struct DyObj { uint64_t* out; const uint64_t *a, *b, *moduli; uint64_t n, nm; };
-struct NttObj { uint64_t* x; const uint64_t *roots, *precon; uint64_t q, n; };
-struct InttObj { uint64_t* x; const uint64_t *roots, *precon; uint64_t q, inv_n, inv_n_w, n; };
-struct KsObj { uint64_t* result; const uint64_t* t; KsKey key; };
 
 struct Engine {
     std::vector<Device> devs;
     int debug = 0;
-    size_t bufsize = 1024;          // FPGA_BUFSIZE: flush when this many objects are queued
-    std::mutex mu_dy, mu_ks, mu_ntt, mu_intt;
-    uint64_t ws_dy = 1, ws_ks = 1, ws_ntt = 1, ws_intt = 1;
-    std::vector<DyObj> q_dy;
-    std::vector<NttObj> q_ntt;
-    std::vector<InttObj> q_intt;
-    std::vector<KsObj> q_ks;
+    size_t max_run = 1024;          // FPGA_BUFSIZE: most objects one runner takes at a time
+    std::mutex mu;                  // guards everything below
+    std::condition_variable cv_work, cv_done;
+    std::deque<Obj> fifo;
+    uint64_t ws[NKIND] = {1, 1, 1, 1}, submitted[NKIND] = {0, 0, 0, 0}, completed[NKIND] = {0, 0, 0, 0};
+    int running_kind = -1, running_runs = 0;                     // runs in flight (all of one primitive)
+    std::unordered_map<const void*, int> inflight_out;           // output arrays of the runs in flight
+    bool stop = false;
+    // keyswitch parameter sets seen so far + the pointer identity of the last call (fast path)
+    std::vector<KsKey> ks_keys;
+    std::map<KsKey, int> ks_index;
+    struct { const uint64_t *moduli, *msf, *twiddles; const uint64_t** keys; uint64_t n, L, K, rns, fp; int plan; } last_ks = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, -1};
 };
 
 Engine* g = nullptr;
@@ -79,101 +121,134 @@ Engine& eng() {
     return *g;
 }
 
-// run fn(dev_index, begin, end) over contiguous shares of [0, count) on every device
-template <class Fn>
-void shard(Engine& e, size_t count, Fn fn) {
-    const size_t nd = std::min(e.devs.size(), count ? count : size_t(1));
-    if (nd <= 1) { fn(0, 0, count); return; }
-    std::vector<std::thread> th;
-    const size_t per = (count + nd - 1) / nd;
-    for (size_t d = 0; d < nd; ++d) {
-        const size_t b = d * per, en = std::min(count, b + per);
-        if (b >= en) break;
-        th.emplace_back([=, &fn] { fn(d, b, en); });
-    }
-    for (auto& t : th) t.join();
-}
-
-void flush_dyadic(Engine& e) {
-    auto q = std::move(e.q_dy);
-    e.q_dy.clear();
-    size_t i = 0;
-    while (i < q.size()) {                     // maximal runs of identical (n, n_moduli)
-        size_t j = i + 1;
-        while (j < q.size() && q[j].n == q[i].n && q[j].nm == q[i].nm) ++j;
-        shard(e, j - i, [&](size_t d, size_t b, size_t en) {
-            std::vector<uint64_t*> out; std::vector<const uint64_t*> a, bb, m;
-            for (size_t k = i + b; k < i + en; ++k) { out.push_back(q[k].out); a.push_back(q[k].a); bb.push_back(q[k].b); m.push_back(q[k].moduli); }
-            int rc = hexl_dyadic_multiply_host(e.devs[d].ctx, out.data(), a.data(), bb.data(), out.size(), q[i].n, m.data(), q[i].nm);
-            if (rc) die("hexl_dyadic_multiply_host", rc);
-        });
-        i = j;
+bool same_params(const Obj& a, const Obj& b) {
+    if (a.kind != b.kind) return false;
+    switch (a.kind) {
+        case DY:   return a.n == b.n && a.s0 == b.s0;                        // n, n_moduli
+        case KS:   return a.plan == b.plan;
+        case NTT:  return a.n == b.n && a.s0 == b.s0;                        // n, modulus (fpga_int.cpp:346-353)
+        case INTT: return a.n == b.n && a.s0 == b.s0;
+        default:   return false;
     }
 }
 
-void flush_ntt(Engine& e) {
-    auto q = std::move(e.q_ntt);
-    e.q_ntt.clear();
-    size_t i = 0;
-    while (i < q.size()) {                     // fence on modulus change (fpga_int.cpp:346-353)
-        size_t j = i + 1;
-        while (j < q.size() && q[j].q == q[i].q && q[j].n == q[i].n) ++j;
-        shard(e, j - i, [&](size_t d, size_t b, size_t en) {
-            std::vector<uint64_t*> x;
-            for (size_t k = i + b; k < i + en; ++k) x.push_back(q[k].x);
-            // tables of the batch's first object, like FPGAObject_NTT::fill_in_data (fpga.cpp:403-411)
-            int rc = hexl_ntt_fwd_host(e.devs[d].ctx, x.data(), x.size(), q[i].roots, q[i].precon, q[i].q, q[i].n);
-            if (rc) die("hexl_ntt_fwd_host", rc);
-        });
-        i = j;
-    }
-}
-
-void flush_intt(Engine& e) {
-    auto q = std::move(e.q_intt);
-    e.q_intt.clear();
-    size_t i = 0;
-    while (i < q.size()) {
-        size_t j = i + 1;
-        while (j < q.size() && q[j].q == q[i].q && q[j].n == q[i].n) ++j;
-        shard(e, j - i, [&](size_t d, size_t b, size_t en) {
-            std::vector<uint64_t*> x;
-            for (size_t k = i + b; k < i + en; ++k) x.push_back(q[k].x);
-            int rc = hexl_ntt_inv_host(e.devs[d].ctx, x.data(), x.size(), q[i].roots, q[i].precon, q[i].q, q[i].inv_n,
-                                       q[i].inv_n_w, q[i].n);
-            if (rc) die("hexl_ntt_inv_host", rc);
-        });
-        i = j;
-    }
-}
-
-hexl_ks_plan* plan_for(Device& dev, const KsKey& k) {
-    auto it = dev.plans.find(k);
+hexl_ks_plan* plan_for(Engine& e, Device& dev, int idx) {
+    auto it = dev.plans.find(idx);
     if (it != dev.plans.end()) return it->second;
+    KsKey k;
+    { std::lock_guard<std::mutex> lk(e.mu); k = e.ks_keys[idx]; }
     hexl_ks_plan* p = nullptr;
     int rc = hexl_ks_plan_create(dev.ctx, k.n, k.L, k.K, k.rns, 2, k.moduli.data(), k.msf.data(), k.twiddles, &p);
     if (rc) die("hexl_ks_plan_create (unsupported keyswitch parameters?)", rc);
     rc = hexl_ks_set_keys(p, k.keys.data());
     if (rc) die("hexl_ks_set_keys", rc);
-    dev.plans.emplace(k, p);
+    dev.plans.emplace(idx, p);
     return p;
 }
 
-void flush_ks(Engine& e) {
-    auto q = std::move(e.q_ks);
-    e.q_ks.clear();
-    size_t i = 0;
-    while (i < q.size()) {                     // fence on parameter / key change (fpga_int.cpp:429-447)
-        size_t j = i + 1;
-        while (j < q.size() && q[j].key == q[i].key) ++j;
-        shard(e, j - i, [&](size_t d, size_t b, size_t en) {
-            std::vector<uint64_t*> r; std::vector<const uint64_t*> t;
-            for (size_t k = i + b; k < i + en; ++k) { r.push_back(q[k].result); t.push_back(q[k].t); }
-            int rc = hexl_keyswitch_host(plan_for(e.devs[d], q[i].key), r.data(), t.data(), r.size());
-            if (rc) die("hexl_keyswitch_host", rc);
-        });
-        i = j;
+void execute(Engine& e, Device& dev, const std::vector<Obj>& run) {
+    const Obj& f = run.front();
+    const size_t cnt = run.size();
+    int rc = 0;
+    switch (f.kind) {
+        case DY: {
+            std::vector<uint64_t*> out(cnt); std::vector<const uint64_t*> a(cnt), b(cnt), m(cnt);
+            for (size_t k = 0; k < cnt; ++k) { out[k] = run[k].out; a[k] = run[k].p0; b[k] = run[k].p1; m[k] = run[k].p2; }
+            rc = hexl_dyadic_multiply_host(dev.ctx, out.data(), a.data(), b.data(), cnt, f.n, m.data(), f.s0);
+            break;
+        }
+        case KS: {
+            std::vector<uint64_t*> r(cnt); std::vector<const uint64_t*> t(cnt);
+            for (size_t k = 0; k < cnt; ++k) { r[k] = run[k].out; t[k] = run[k].p0; }
+            rc = hexl_keyswitch_host(plan_for(e, dev, f.plan), r.data(), t.data(), cnt);
+            break;
+        }
+        case NTT: {
+            std::vector<uint64_t*> x(cnt);
+            for (size_t k = 0; k < cnt; ++k) x[k] = run[k].out;
+            // tables of the run's first object, like FPGAObject_NTT::fill_in_data (fpga.cpp:403-411)
+            rc = hexl_ntt_fwd_host(dev.ctx, x.data(), cnt, f.p0, f.p1, f.s0, f.n);
+            break;
+        }
+        case INTT: {
+            std::vector<uint64_t*> x(cnt);
+            for (size_t k = 0; k < cnt; ++k) x[k] = run[k].out;
+            rc = hexl_ntt_inv_host(dev.ctx, x.data(), cnt, f.p0, f.p1, f.s0, f.s1, f.s2, f.n);
+            break;
+        }
+        default: break;
     }
+    if (rc) die(kind_name[f.kind], rc);
+}
+
+// the runner of device `di` (Device::run, fpga.cpp:780-866)
+void runner_loop(Engine* ep, size_t di) {
+    Engine& e = *ep;
+    Device& dev = e.devs[di];
+    std::vector<Obj> run;
+    std::unique_lock<std::mutex> lk(e.mu);
+    for (;;) {
+        run.clear();
+        e.cv_work.wait(lk, [&] {
+            if (e.stop) return true;
+            if (e.fifo.empty()) return false;
+            const Obj& h = e.fifo.front();
+            if (e.running_runs > 0 && e.running_kind != (int)h.kind) return false;      // primitives never overlap
+            return e.inflight_out.find(h.out) == e.inflight_out.end();                   // output busy on another device
+        });
+        if (e.stop) return;
+        // the head run: same primitive, same parameters, no output another device is still producing. With several
+        // devices a runner leaves the others their share of what is queued right now.
+        size_t avail = 0;
+        while (avail < e.fifo.size() && avail < e.max_run && same_params(e.fifo.front(), e.fifo[avail]) &&
+               e.inflight_out.find(e.fifo[avail].out) == e.inflight_out.end())
+            ++avail;
+        const size_t nd = e.devs.size();
+        const size_t take = nd > 1 ? std::max<size_t>(1, (avail + nd - 1) / nd) : avail;
+        for (size_t k = 0; k < take; ++k) { run.push_back(e.fifo.front()); e.fifo.pop_front(); }
+        for (const Obj& o : run) ++e.inflight_out[o.out];
+        e.running_kind = (int)run.front().kind;
+        ++e.running_runs;
+        if (e.debug)
+            std::fprintf(stderr, "[hexl-fpga/mi355x] device %zu: %zu x %s (n = %lu), %zu still queued\n", di, run.size(),
+                         kind_name[run.front().kind], (unsigned long)run.front().n, e.fifo.size());
+        lk.unlock();
+        if (nd > 1) e.cv_work.notify_all();                       // the rest of the run is for the other runners
+        execute(e, dev, run);
+        lk.lock();
+        for (const Obj& o : run) {
+            auto it = e.inflight_out.find(o.out);
+            if (--it->second == 0) e.inflight_out.erase(it);
+        }
+        e.completed[run.front().kind] += run.size();
+        --e.running_runs;
+        e.cv_done.notify_all();
+        e.cv_work.notify_all();
+    }
+}
+
+// append one object; worksize 1 => wait for it (fpga_int.cpp:459-461)
+void submit(Engine& e, const Obj& o) {
+    std::unique_lock<std::mutex> lk(e.mu);
+    e.fifo.push_back(o);
+    const uint64_t mine = ++e.submitted[o.kind];
+    e.cv_work.notify_one();
+    if (e.ws[o.kind] == 1) e.cv_done.wait(lk, [&] { return e.completed[o.kind] >= mine; });
+}
+
+bool completed(Kind k) {
+    Engine& e = eng();
+    std::unique_lock<std::mutex> lk(e.mu);
+    const uint64_t upto = e.submitted[k];
+    e.cv_done.wait(lk, [&] { return e.completed[k] >= upto; });
+    e.ws[k] = 1;                                                   // fpga_int.cpp:229,308,389,504
+    return true;
+}
+
+void set_ws(Kind k, uint64_t ws) {
+    Engine& e = eng();
+    std::lock_guard<std::mutex> lk(e.mu);
+    e.ws[k] = ws ? ws : 1;
 }
 
 bool pow2_in(uint64_t n, uint64_t lo, uint64_t hi) { return n >= lo && n <= hi && (n & (n - 1)) == 0; }
@@ -187,27 +262,36 @@ void acquire_FPGA_resources() {
     if (g) return;
     Engine* e = new Engine();
     e->debug = (int)env_ul("FPGA_DEBUG", 0);
-    e->bufsize = env_ul("FPGA_BUFSIZE", 1024);
-    if (e->bufsize == 0) e->bufsize = 1;
+    e->max_run = env_ul("FPGA_BUFSIZE", 1024);
+    if (e->max_run == 0) e->max_run = 1;
     // RUN_CHOICE (0 CPU / 1 emulator / 2 FPGA in the reference, fpga_int.cpp:40-60) has one meaning here:
     // the MI355X path. There is deliberately no CPU fallback.
     const unsigned long want = env_ul("NUM_DEV", 1);
+    // HEXL_DEV_ALIAS=1 (tests on a one-GPU box): NUM_DEV contexts share the visible GPUs round robin
+    const bool alias = env_ul("HEXL_DEV_ALIAS", 0) == 1;
+    const int ngpu = hexl_device_count();
     for (unsigned long d = 0; d < (want ? want : 1); ++d) {
         Device dev;
-        int rc = hexl_ctx_create((int)d, &dev.ctx);
+        const int id = alias && ngpu > 0 ? (int)(d % (unsigned long)ngpu) : (int)d;
+        int rc = hexl_ctx_create(id, &dev.ctx);
         if (rc) {
             if (d == 0) die("no MI355X device available (hexl_ctx_create)", rc);
             break;                              // fewer GPUs than NUM_DEV: use what exists
         }
         char buf[256];
         if (hexl_ctx_describe(dev.ctx, buf, sizeof(buf)) == 0) std::printf("%s\n", buf);
-        e->devs.push_back(dev);
+        e->devs.push_back(std::move(dev));
     }
+    for (size_t d = 0; d < e->devs.size(); ++d) e->devs[d].runner = std::thread(runner_loop, e, d);
     g = e;
 }
 
 void release_FPGA_resources() {
     if (!g) return;
+    for (int k = 0; k < NKIND; ++k) completed((Kind)k);           // drain what is still queued
+    { std::lock_guard<std::mutex> lk(g->mu); g->stop = true; }
+    g->cv_work.notify_all();
+    for (auto& d : g->devs) d.runner.join();
     for (auto& d : g->devs) {
         for (auto& kv : d.plans) hexl_ks_plan_destroy(kv.second);
         hexl_ctx_destroy(d.ctx);
@@ -217,37 +301,20 @@ void release_FPGA_resources() {
 }
 
 // ---------------------------------------------------------------- DyadicMultiply
-void set_worksize_DyadicMultiply(uint64_t ws) {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_dy);
-    e.ws_dy = ws ? ws : 1;
-}
+void set_worksize_DyadicMultiply(uint64_t ws) { set_ws(DY, ws); }
 
 void DyadicMultiply(uint64_t* results, const uint64_t* operand1, const uint64_t* operand2, uint64_t n,
                     const uint64_t* moduli, uint64_t n_moduli) {
     REQUIRE(results && operand1 && operand2 && moduli, "DyadicMultiply: null pointer");
     REQUIRE(n > 0, "DyadicMultiply: n must be a positive integer");                        // dyadic_multiply.cpp:19
     REQUIRE(n_moduli > 0, "DyadicMultiply: requires n_moduli > 0");
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_dy);
-    e.q_dy.push_back({results, operand1, operand2, moduli, n, n_moduli});
-    if (e.ws_dy == 1 || e.q_dy.size() >= e.bufsize) flush_dyadic(e);
+    submit(eng(), Obj{DY, results, operand1, operand2, moduli, n, n_moduli, 0, 0, -1});
 }
 
-bool DyadicMultiplyCompleted() {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_dy);
-    flush_dyadic(e);
-    e.ws_dy = 1;
-    return true;
-}
+bool DyadicMultiplyCompleted() { return completed(DY); }
 
 // ---------------------------------------------------------------- KeySwitch
-void set_worksize_KeySwitch(uint64_t ws) {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_ks);
-    e.ws_ks = ws ? ws : 1;
-}
+void set_worksize_KeySwitch(uint64_t ws) { set_ws(KS, ws); }
 
 void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n, uint64_t decomp_modulus_size,
                uint64_t key_modulus_size, uint64_t rns_modulus_size, uint64_t key_component_count,
@@ -259,76 +326,66 @@ void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n, 
     REQUIRE(key_component_count == 2, "KeySwitch: requires key_component_count = 2");
     REQUIRE(decomp_modulus_size < key_modulus_size && key_modulus_size <= 16,
             "KeySwitch: requires decomp_modulus_size < key_modulus_size <= 16");            // reference: <= 7
-    KsKey k;
-    k.n = n; k.L = decomp_modulus_size; k.K = key_modulus_size; k.rns = rns_modulus_size;
-    k.moduli.assign(moduli, moduli + key_modulus_size);
-    k.msf.assign(modswitch_factors, modswitch_factors + key_modulus_size);
-    k.keys.assign(k_switch_keys, k_switch_keys + decomp_modulus_size);
-    k.twiddles = twiddle_factors;
     Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_ks);
-    e.q_ks.push_back({result, t_target_iter_ptr, std::move(k)});
-    if (e.ws_ks == 1 || e.q_ks.size() >= e.bufsize) flush_ks(e);
+    int plan;
+    for (uint64_t d = 0; d < decomp_modulus_size; ++d) REQUIRE(k_switch_keys[d], "KeySwitch: null key pointer");
+    const uint64_t fp = key_fingerprint(k_switch_keys, decomp_modulus_size, key_modulus_size, n);
+    {
+        std::lock_guard<std::mutex> lk(e.mu);
+        auto& l = e.last_ks;
+        // same argument POINTERS and sizes as the previous call: same parameter set (fpga_int.cpp:429-447 compares
+        // pointers too; the arrays are caller-owned and immutable until KeySwitchCompleted)
+        if (l.plan >= 0 && l.moduli == moduli && l.msf == modswitch_factors && l.keys == k_switch_keys &&
+            l.twiddles == twiddle_factors && l.n == n && l.L == decomp_modulus_size && l.K == key_modulus_size &&
+            l.rns == rns_modulus_size && l.fp == fp && !e.ks_keys.empty() &&
+            std::equal(e.ks_keys[l.plan].keys.begin(), e.ks_keys[l.plan].keys.end(), k_switch_keys)) {
+            plan = l.plan;
+        } else {
+            KsKey k;
+            k.n = n; k.L = decomp_modulus_size; k.K = key_modulus_size; k.rns = rns_modulus_size; k.fp = fp;
+            k.moduli.assign(moduli, moduli + key_modulus_size);
+            k.msf.assign(modswitch_factors, modswitch_factors + key_modulus_size);
+            k.keys.assign(k_switch_keys, k_switch_keys + decomp_modulus_size);
+            k.twiddles = twiddle_factors;
+            auto it = e.ks_index.find(k);
+            if (it == e.ks_index.end()) {
+                it = e.ks_index.emplace(k, (int)e.ks_keys.size()).first;
+                e.ks_keys.push_back(k);
+            }
+            plan = it->second;
+            l = {moduli, modswitch_factors, twiddle_factors, k_switch_keys, n, decomp_modulus_size, key_modulus_size,
+                 rns_modulus_size, fp, plan};
+        }
+    }
+    submit(e, Obj{KS, result, t_target_iter_ptr, nullptr, nullptr, n, 0, 0, 0, plan});
 }
 
-bool KeySwitchCompleted() {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_ks);
-    flush_ks(e);
-    e.ws_ks = 1;
-    return true;
-}
+bool KeySwitchCompleted() { return completed(KS); }
 
 // ---------------------------------------------------------------- _NTT / _INTT
-void _set_worksize_NTT(uint64_t ws) {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_ntt);
-    e.ws_ntt = ws ? ws : 1;
-}
+void _set_worksize_NTT(uint64_t ws) { set_ws(NTT, ws); }
 
 void _NTT(uint64_t* operand, const uint64_t* root_of_unity_powers, const uint64_t* precon_root_of_unity_powers,
           uint64_t coeff_modulus, uint64_t n) {
     REQUIRE(operand && root_of_unity_powers && precon_root_of_unity_powers, "_NTT: null pointer");
     REQUIRE(pow2_in(n, 1024, 32768), "_NTT: requires n = 16384 (1024..32768 accepted here)");   // ntt.cpp:24
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_ntt);
-    e.q_ntt.push_back({operand, root_of_unity_powers, precon_root_of_unity_powers, coeff_modulus, n});
-    if (e.ws_ntt == 1 || e.q_ntt.size() >= e.bufsize) flush_ntt(e);
+    submit(eng(), Obj{NTT, operand, root_of_unity_powers, precon_root_of_unity_powers, nullptr, n, coeff_modulus, 0, 0, -1});
 }
 
-bool _NTTCompleted() {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_ntt);
-    flush_ntt(e);
-    e.ws_ntt = 1;
-    return true;
-}
+bool _NTTCompleted() { return completed(NTT); }
 
-void _set_worksize_INTT(uint64_t ws) {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_intt);
-    e.ws_intt = ws ? ws : 1;
-}
+void _set_worksize_INTT(uint64_t ws) { set_ws(INTT, ws); }
 
 void _INTT(uint64_t* operand, const uint64_t* inv_root_of_unity_powers,
            const uint64_t* precon_inv_root_of_unity_powers, uint64_t coeff_modulus, uint64_t inv_n, uint64_t inv_n_w,
            uint64_t n) {
     REQUIRE(operand && inv_root_of_unity_powers && precon_inv_root_of_unity_powers, "_INTT: null pointer");
     REQUIRE(pow2_in(n, 1024, 32768), "_INTT: requires n = 16384 (1024..32768 accepted here)");  // intt.cpp:25
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_intt);
-    e.q_intt.push_back({operand, inv_root_of_unity_powers, precon_inv_root_of_unity_powers, coeff_modulus, inv_n,
-                        inv_n_w, n});
-    if (e.ws_intt == 1 || e.q_intt.size() >= e.bufsize) flush_intt(e);
+    submit(eng(), Obj{INTT, operand, inv_root_of_unity_powers, precon_inv_root_of_unity_powers, nullptr, n, coeff_modulus,
+                      inv_n, inv_n_w, -1});
 }
 
-bool _INTTCompleted() {
-    Engine& e = eng();
-    std::lock_guard<std::mutex> lk(e.mu_intt);
-    flush_intt(e);
-    e.ws_intt = 1;
-    return true;
-}
+bool _INTTCompleted() { return completed(INTT); }
 
 }  // namespace hexl
 }  // namespace intel

@@ -31,6 +31,10 @@ extern "C" {
 typedef struct hexl_ctx hexl_ctx;         /* one per GPU: stream + scratch */
 typedef struct hexl_ks_plan hexl_ks_plan; /* keyswitch parameter set: tables + keys on device */
 
+/* number of gfx950 devices visible to the process (0 if none); what NUM_DEV is clamped to
+ * (DevicePool, host/src/fpga.cpp:1646-1673) */
+int hexl_device_count(void);
+
 /* replaces acquire_/release_FPGA_resources' device half (host/src/fpga.cpp:1646-1685):
  * binds `device`, creates the stream. */
 int hexl_ctx_create(int device, hexl_ctx** out);

@@ -132,6 +132,43 @@ static void test_keyswitch_aliased_results() {
     CHECK(r == ref, "aliased result arrays inside one batch");
 }
 
+// benchmark/bench_keyswitch.cpp:113-131: ITER x (two test vectors) in ONE worksize window, every iteration accumulating
+// into the same two result arrays. With HEXL_HOST_SUB_MB=1 every object is its own staging sub-batch, so the
+// accumulating unpacks of consecutive sub-batches (and, with NUM_DEV > 1, of different devices) must be ordered.
+// KeySwitch adds out(t) to result, so after `iters` rounds result = r0 + iters * out(t) (mod q_i).
+static void test_keyswitch_aliased_across_subbatches(int repeats) {
+    const int iters = 40;
+    KsSetup ks(8192, 3, 4, 91);
+    vec t[2], r0[2], out[2];
+    for (int v = 0; v < 2; ++v) {
+        ks.make(t[v], r0[v], 20 + v);
+        out[v].assign(r0[v].size(), 0);
+        ks.expect(out[v], t[v]);                                  // out(t): the oracle on a zero result
+    }
+    for (int rep = 0; rep < repeats; ++rep) {
+        vec r[2] = {r0[0], r0[1]};
+        set_worksize_KeySwitch(2 * iters);
+        for (int it = 0; it < iters; ++it)
+            for (int v = 0; v < 2; ++v)
+                KeySwitch(r[v].data(), t[v].data(), ks.n, ks.L, ks.K, ks.L + 1, 2, ks.moduli.data(), ks.key_ptrs.data(), ks.msf.data());
+        KeySwitchCompleted();
+        for (int v = 0; v < 2; ++v) {
+            bool ok = true;
+            for (uint64_t k = 0; k < 2 && ok; ++k)
+                for (uint64_t i = 0; i < ks.L && ok; ++i) {
+                    const uint64_t q = ks.moduli[i];
+                    for (uint64_t j = 0; j < ks.n; ++j) {
+                        const size_t at = (k * ks.L + i) * ks.n + j;
+                        const uint64_t want = (uint64_t)(((unsigned __int128)out[v][at] * iters + r0[v][at]) % q);
+                        if (r[v][at] != want) { ok = false; break; }
+                    }
+                }
+            CHECK(ok, "aliased results across sub-batches: repeat %d vector %d", rep, v);
+            if (!ok) return;
+        }
+    }
+}
+
 // mixed op types and parameter changes inside one worksize window (fences), like
 // tests/test_dyadic_multiply_keyswitch.cpp:295-313
 static void test_mixed_and_fences() {
@@ -161,8 +198,14 @@ static void test_mixed_and_fences() {
     CHECK(xa == ea && xb == eb, "NTT fence on modulus change");
 }
 
-int main() {
+int main(int argc, char** argv) {
     acquire_FPGA_resources();
+    if (argc > 1 && !std::strcmp(argv[1], "alias")) {             // the ordering stress on its own: alias [repeats]
+        test_keyswitch_aliased_across_subbatches(argc > 2 ? atoi(argv[2]) : 50);
+        release_FPGA_resources();
+        std::printf(failures ? "CXX API: %d FAILURE(S)\n" : "CXX API: ALL PASSED\n", failures);
+        return failures ? 1 : 0;
+    }
     for (unsigned bits : {20u, 32u, 55u, 62u}) test_ntt_intt(16384, bits, 4);     // test_fwd_ntt.cpp:119-170 primes
     test_ntt_intt(1024, 30, 3);
     test_dyadic(8192, 7, 4);
@@ -171,6 +214,7 @@ int main() {
     test_keyswitch(8192, 5, 7, 2);                                                // the 8192_5_7_6_2-like shape
     test_keyswitch(1024, 1, 2, 2);
     test_keyswitch_aliased_results();
+    test_keyswitch_aliased_across_subbatches(2);
     test_mixed_and_fences();
     release_FPGA_resources();
     std::printf(failures ? "CXX API: %d FAILURE(S)\n" : "CXX API: ALL PASSED\n", failures);
