@@ -35,15 +35,20 @@ def ks_alg_bytes(n, L):
     return (L + 2 * 2 * L) * n * 8
 
 
-def device_inputs(hx, orc_mod, case, batch, dev, distinct=8):
-    """batch instances built from `distinct` independent splitmix instances (keeps host prep cheap; every
-    instance is still full-entropy data mod its limb)"""
+def device_inputs(hx, orc_mod, case, batch, dev, distinct=None):
+    """`batch` independent instances generated on the device: every limb uniform in [0, q_i) (torch.randint, seeded),
+    t_target[b][L][n] and result[b][2][L][n] as int64 bit patterns of the uint64 words"""
     import torch
-    ts, rs = zip(*[case.inputs(orc_mod, b) for b in range(min(distinct, batch))])
-    t = hx.as_i64(np.stack(ts)).to(dev)
-    r = hx.as_i64(np.stack(rs)).to(dev)
-    reps = (batch + t.shape[0] - 1) // t.shape[0]
-    return t.repeat(reps, 1)[:batch].contiguous(), r.repeat(reps, 1)[:batch].contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + case.seed)
+    n, L = case.n, case.L
+    t = torch.empty((batch, L, n), dtype=torch.int64, device=dev)
+    r = torch.empty((batch, 2, L, n), dtype=torch.int64, device=dev)
+    for i in range(L):
+        q = int(case.moduli[i])
+        t[:, i].random_(0, q, generator=g)
+        r[:, :, i].random_(0, q, generator=g)
+    return t.reshape(batch, -1), r.reshape(batch, -1)
 
 
 def time_ntt(hx, ctx, orc_mod, dev, batch, iters):
@@ -96,27 +101,54 @@ def time_dyadic(hx, ctx, orc_mod, dev, batch=4096, n=8192, nm=4, iters=5):
     return {"ms_per_launch": ms, "items_per_s": batch / (ms * 1e-3), "alg_GBps": batch * 7 * nm * n * 8 / (ms * 1e-3) / 1e9}
 
 
-def cpu_baseline(orc_mod, case, budget_s=12.0):
-    """the oracle (C restatement of the reference algorithm, single thread) timed on this host"""
-    t, r = case.inputs(orc_mod, 0)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        case.expected(orc_mod, t, r)
-        done += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or done >= 1024:
-            break
-    return {"value": done / el, "unit": "keyswitches/s", "cores": 1, "kind": "port",
-            "sample": f"{done} keyswitch(es) N={case.n} L={case.L} K={case.K}, oracle/hexl_oracle.c -O3, 1 thread of "
-                      f"{os.cpu_count()} host cores, {el:.1f}s"}
+def cpu_baseline(orc_mod, case, budget_s=10.0):
+    """oracle/cpu_baseline.c (Harvey/Shoup port of the reference's CPU algorithms, built -O3 -march=native on THIS host)
+    timed on the host cores: one thread, then OpenMP over independent ciphertexts on every core the process may use.
+    Bounded sample: ~budget_s seconds per leg. Checked against the line-by-line oracle on one instance first."""
+    cb = orc_mod.CpuKeySwitch(case.n, case.L, case.K, case.moduli, case.keys, case.modswitch)
+    t1, r1 = case.inputs(orc_mod, 0)
+    got = r1.copy()
+    cb.keyswitch_batch(got, t1, 1)
+    assert np.array_equal(got, case.expected(orc_mod, t1, r1)), "CPU port disagrees with the oracle"
+    cores = len(os.sched_getaffinity(0))
+    threads = min(cb.lib.cb_max_threads(), cores)
+    ts, rs = zip(*[case.inputs(orc_mod, b) for b in range(8)])
+
+    def leg(nthreads, batch):
+        t = np.tile(np.concatenate(ts), (batch + 7) // 8)[:batch * case.L * case.n].copy()
+        r = np.tile(np.concatenate(rs), (batch + 7) // 8)[:batch * 2 * case.L * case.n].copy()
+        cb.keyswitch_batch(r, t, nthreads)                       # warm-up (page faults, thread pool)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            cb.keyswitch_batch(r, t, nthreads)
+            done += batch
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                return done / el, done, el
+
+    v1, n1, e1 = leg(1, 8)
+    va, na, ea = leg(threads, 2 * threads)
+    cb.close()
+    return {"value": va, "unit": "keyswitches/s", "cores": threads, "kind": "port", "value_1t": v1,
+            "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
+            "sample": f"{na} keyswitches N={case.n} L={case.L} K={case.K} in {ea:.1f}s on {threads} OpenMP threads "
+                      f"(one ciphertext per thread, affinity mask of {cores} of {os.cpu_count()} cores); 1 thread: {n1} in "
+                      f"{e1:.1f}s; oracle/cpu_baseline.c (Harvey/Shoup port of the reference's CPU algorithms, "
+                      f"gcc -O3 -march=native -fopenmp; Intel HEXL itself is not in the image)"}
+
+
+def ctx_cus(ctx):
+    import re
+    m = re.search(r"(\d+) CUs", ctx.describe())
+    return int(m.group(1)) if m else 256
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="keyswitches per GPU per step")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="keyswitches per GPU per step (44 GB of ciphertexts at the default)")
     ap.add_argument("--decomp", type=int, default=7, help="decomp_modulus_size L (key_modulus_size = L+1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -150,6 +182,12 @@ def main():
     plan.set_keys(case.keys)
     d_t, d_r = device_inputs(hx, orc_mod, case, a.batch, dev)
 
+    # in-run check of the measured path: instance 0 of the first full-batch launch against the oracle
+    t0_host, r0_host = hx.to_u64(d_t[0]).copy(), hx.to_u64(d_r[0]).copy()
+    plan.keyswitch(d_r, d_t, a.batch)
+    ctx.sync()
+    verified = bool(np.array_equal(hx.to_u64(d_r[0]), case.expected(orc_mod, t0_host, r0_host)))
+    assert verified, "keyswitch output differs from the oracle"
     for _ in range(a.warmup):
         plan.keyswitch(d_r, d_t, a.batch)
     barrier()
@@ -173,6 +211,7 @@ def main():
         "metric": "keyswitches/sec at N=16384, decomp=7", "value": value, "unit": "keyswitches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "verified_vs_oracle": verified,
         "config": {"workload": f"keyswitch N={N} decomp_modulus_size={L} key_modulus_size={K} 52-bit primes "
                                f"(GeneratePrimes(K,51,N)), kcc=2, batch {a.batch}/GPU resident in HBM",
                    "parallelism": f"{world} independent shard(s), no collective"},
@@ -181,27 +220,42 @@ def main():
         alg = ks_alg_bytes(N, L)
         ach = alg * a.batch * a.steps / (dev_ms * 1e-3) / 1e9          # this rank, device-timed
         stage = plan.time_stages(d_r, d_t, min(a.batch, 256), 3)
-        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE
-        # summed over the pipeline's kernels, separate --pmc runs); scaled from the profiled batch to this batch
-        traffic = None
+        us_per_ks = dev_ms * 1e3 / (a.batch * a.steps)
+        # Both bounds, recomputable from profiles/ alone (tools/pmc_summary.py writes the two JSON files from the PMC
+        # passes of tools/pmc_quick.sh): HBM-side bytes = sum over the pipeline's kernels of 2*FETCH_SIZE + WRITE_SIZE;
+        # FP64 issue time = VALU instructions per keyswitch (SQ_INSTS_VALU) x 4 cycles (one wave64 FP64 instruction on
+        # a SIMD, MI355X_MICROARCH.md: 78.6 TFLOP/s vector FP64) / (4 SIMDs x CUs) / shader clock under this load
+        traffic, traffic_src, alu = None, None, None
         tj = ROOT / "profiles" / "traffic_latest.json"
         if tj.exists():
             t = json.loads(tj.read_text())
             if t.get("L") == L:
                 traffic = t["keyswitch_traffic_bytes_per_unit"] * a.batch
+                traffic_src = "profiles/traffic_latest.json (PMC passes of tools/pmc_quick.sh, per keyswitch x batch)"
+        aj = ROOT / "profiles" / "alu_latest.json"
+        if aj.exists():
+            t = json.loads(aj.read_text())
+            if t.get("L") == L:
+                clk = t.get("shader_clock_ghz", 2.0)
+                issue_us = t["valu_wave_instructions_per_keyswitch"] * 4.0 / (4 * ctx_cus(ctx)) / (clk * 1e3)
+                alu = {"bound": "valu_fp64", "valu_wave_instructions_per_keyswitch": t["valu_wave_instructions_per_keyswitch"],
+                       "cycles_per_wave_instruction": 4, "simds": 4 * ctx_cus(ctx), "shader_clock_ghz": clk,
+                       "issue_us_per_keyswitch": issue_us, "measured_us_per_keyswitch": us_per_ks,
+                       "achieved_frac": issue_us / us_per_ks, "source": "profiles/alu_latest.json (SQ_INSTS_VALU per kernel)"}
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "alg_bytes_per_launch": alg * a.batch,
-                           "kernel": "keyswitch pipeline (k_ksf_up + k_ksf_mac + k_ksf_intt_sp + k_ksf_moddown)",
+                           "kernel": "keyswitch pipeline (k_ksx_intt + k_ksx_special + k_ksx_main; chunks of 256 keyswitches)",
                            "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps,
-                           # the pipeline runs in chunks of 256 keyswitches; per chunk, from hipEvents on the launch
-                           # stream (compare avg_us of the same kernels in profiles/*kernel_trace*)
-                           "dominant_kernel": {"name": "k_ksf_up (steps 1-2)", "ms_per_chunk": stage[1],
-                                               "share_of_pipeline": stage[1] / stage[0],
-                                               "chunk": min(a.batch, 256)}}
-        extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "steps_1_2_inverse_and_modup": stage[1],
-                                                             "steps_3_4_mac_and_special_inverse": stage[2],
-                                                             "steps_5_7_moddown": stage[3]},
+                           # per chunk of 256, from hipEvents on the launch stream (compare avg_us in profiles/*kernel_trace*)
+                           "dominant_kernel": {"name": "k_ksx_main (steps 2-3 of the L decomposition limbs, steps 5-7)",
+                                               "ms_per_chunk": stage[3], "share_of_pipeline": stage[3] / stage[0],
+                                               "chunk": min(a.batch, 256)},
+                           # the binding bound: 72 N-point transforms of exact 52-bit arithmetic per 4.6 MB
+                           "alu": alu}
+        extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "step_1_inverse_transforms": stage[1],
+                                                             "steps_2_4_special_limb": stage[2],
+                                                             "steps_2_3_5_7_decomposition_limbs": stage[3]},
                  "device": ctx.describe()}
         if not a.no_extra:
             extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)
@@ -210,19 +264,20 @@ def main():
                 cs = KsCase(orc_mod, N, Lx, Kx, seed=99, moduli=moduli)
                 pl = hx.KeySwitchPlan(ctx, N, Lx, Kx, Kx, 2, cs.moduli, cs.modswitch)
                 pl.set_keys(cs.keys)
-                tx, rx = device_inputs(hx, orc_mod, cs, a.batch, dev)
-                pl.keyswitch(rx, tx, a.batch)
+                nbx = min(a.batch, 2048)
+                tx, rx = device_inputs(hx, orc_mod, cs, nbx, dev)
+                pl.keyswitch(rx, tx, nbx)
                 torch.cuda.synchronize()
                 f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 f0.record()
                 for _ in range(3):
-                    pl.keyswitch(rx, tx, a.batch)
+                    pl.keyswitch(rx, tx, nbx)
                 f1.record()
                 torch.cuda.synchronize()
                 ms = f0.elapsed_time(f1) / 3
                 pl.close()
-                return {"keyswitches_per_s": a.batch / (ms * 1e-3),
-                        "alg_GBps": ks_alg_bytes(N, Lx) * a.batch / (ms * 1e-3) / 1e9}
+                return {"keyswitches_per_s": nbx / (ms * 1e-3), "batch": nbx,
+                        "alg_GBps": ks_alg_bytes(N, Lx) * nbx / (ms * 1e-3) / 1e9}
             # the reference-representable shape 16384_6_7_7_2 (decomp 6, 7 key moduli), 52-bit primes
             extra["keyswitch_16384_6_7_7_2"] = other_shape(6, 7)
             # the same shape with 48-bit primes (SEAL's default parameter sizes for N=16384): longer lazy-reduction period

@@ -147,3 +147,52 @@ def keyswitch(result: np.ndarray, t_target: np.ndarray, n, L, K, rns, moduli, ke
                              None if twiddles is None else p(twiddles))
     assert rc == 0
     return result
+
+
+# ---------------------------------------------------------------- bench.py's CPU leg (oracle/cpu_baseline.c)
+_cb = {}
+
+
+def cpu_baseline_lib(march: str = "native") -> ctypes.CDLL:
+    """build (on THIS host, -march=native by default) and load the OpenMP CPU port that bench.py times"""
+    if march not in _cb:
+        if march == "native":                                  # never trust a shipped "native" build: rebuild here
+            (HERE / "_native" / "libcpubase.native.so").unlink(missing_ok=True)
+        subprocess.run(["make", "-C", str(HERE), "-s", "cpubase", f"MARCH={march}"], check=True)
+        L = ctypes.CDLL(str(HERE / "_native" / f"libcpubase.{march}.so"))
+        L.cb_plan_create.restype = ctypes.c_void_p
+        L.cb_plan_create.argtypes = [u64, u64, u64, P, ctypes.POINTER(P), P]
+        L.cb_plan_destroy.restype = None; L.cb_plan_destroy.argtypes = [ctypes.c_void_p]
+        L.cb_keyswitch_batch.restype = ctypes.c_int
+        L.cb_keyswitch_batch.argtypes = [ctypes.c_void_p, P, P, u64, ctypes.c_int]
+        L.cb_ntt_fwd_batch.restype = ctypes.c_int
+        L.cb_ntt_fwd_batch.argtypes = [ctypes.c_void_p, u64, P, u64, ctypes.c_int]
+        L.cb_max_threads.restype = ctypes.c_int; L.cb_max_threads.argtypes = []
+        _cb[march] = L
+    return _cb[march]
+
+
+class CpuKeySwitch:
+    """tables + key Shoup factors precomputed once; keyswitch_batch(results[b][2][L][n], ts[b][L][n], threads)"""
+
+    def __init__(self, n, L, K, moduli, keys, modswitch, march="native"):
+        self.lib = cpu_baseline_lib(march)
+        self.n, self.L, self.K = n, L, K
+        self._keys = [np.ascontiguousarray(k, dtype=np.uint64) for k in keys]          # keep alive
+        self._karr = (P * len(keys))(*[p(k) for k in self._keys])
+        self._mod = np.ascontiguousarray(moduli, dtype=np.uint64)
+        self._msf = np.ascontiguousarray(modswitch, dtype=np.uint64)
+        self.h = self.lib.cb_plan_create(n, L, K, p(self._mod), self._karr, p(self._msf))
+
+    def keyswitch_batch(self, results: np.ndarray, ts: np.ndarray, threads: int = 0) -> int:
+        batch = ts.size // (self.L * self.n)
+        assert results.size == batch * 2 * self.L * self.n
+        return self.lib.cb_keyswitch_batch(self.h, p(results), p(ts), batch, threads)
+
+    def ntt_fwd_batch(self, x: np.ndarray, modulus_index: int = 0, threads: int = 0) -> int:
+        return self.lib.cb_ntt_fwd_batch(self.h, modulus_index, p(x), x.size // self.n, threads)
+
+    def close(self):
+        if self.h:
+            self.lib.cb_plan_destroy(self.h)
+            self.h = None

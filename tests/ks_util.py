@@ -50,3 +50,64 @@ def primes_below(orc, count, limit, n):
             out.append(v)
         v -= 2 * n
     return out
+
+
+class RlweCase:
+    """Real RLWE switching keys with special prime P = moduli[K-1]: key d, limb i holds (b, a) with
+    b = -a*s_old + e + (i == d ? P : 0) * s_new in the NTT domain. check(res) asserts that
+    res0 + res1*s_old == t*s_new + small noise in every limb and that the limbs agree on the noise polynomial -- what
+    the reference's SEAL test asserts end to end (experimental/bridge-seal/tests/keyswitch-example.cpp:119-206)."""
+
+    def __init__(self, orc, n, L, K, bits, seed=2):
+        self.orc, self.n, self.L, self.K = orc, n, L, K
+        self.qs = [int(v) for v in orc.primes(K, bits, n)]
+        qs, P = self.qs, self.qs[K - 1]
+        rng = np.random.default_rng(seed)
+        self.s_old = rng.integers(-1, 2, n)
+        self.s_new = rng.integers(-1, 2, n)
+        self.blks = []
+        for q in qs:
+            b = np.zeros(4 * n, dtype=np.uint64)
+            orc.orc().orc_tables_keyswitch(n, q, orc.orc().orc_minimal_primitive_root(2 * n, q), orc.p(b))
+            self.blks.append(b)
+        self.keys = []
+        for d in range(L):
+            e = rng.integers(-3, 4, n)
+            key = np.zeros(2 * K * n, dtype=np.uint64)
+            for i in range(K):
+                a = self.ntt(rng.integers(0, 2**62, n).astype(object) % qs[i], i)
+                b = (-a * self.ntt(self.s_old, i) + self.ntt(e, i) + (P % qs[i] if i == d else 0) * self.ntt(self.s_new, i)) % qs[i]
+                key[(0 * K + i) * n:(0 * K + i + 1) * n] = np.array(b, dtype=np.uint64)
+                key[(1 * K + i) * n:(1 * K + i + 1) * n] = np.array(a, dtype=np.uint64)
+            self.keys.append(key)
+        self.moduli = np.array(qs, dtype=np.uint64)
+        self.modswitch = np.array([pow(P, -1, q) if q != P else 1 for q in qs], dtype=np.uint64)
+        # the polynomial being switched, given in NTT form per limb (a consistent RNS element)
+        t_int = rng.integers(0, 2**62, n).astype(object)
+        self.t = np.concatenate([np.array(self.ntt(t_int % qs[d], d), dtype=np.uint64) for d in range(L)])
+
+    def ntt(self, poly, i):
+        n, q = self.n, self.qs[i]
+        x = np.array([int(v) % q for v in poly], dtype=np.uint64)
+        self.orc.orc().orc_ks_ntt(self.orc.p(x), n, q, self.orc.p(self.blks[i][2 * n:3 * n]))
+        return x.astype(object)
+
+    def intt(self, x, i):
+        n, q = self.n, self.qs[i]
+        y = np.array([int(v) % q for v in x], dtype=np.uint64)
+        self.orc.orc().orc_ks_intt(self.orc.p(y), n, q, self.orc.p(self.blks[i][0:n]))
+        return y.astype(object)
+
+    def check(self, res, noise_bits=24):
+        n, L, qs = self.n, self.L, self.qs
+        noises = []
+        for i in range(L):
+            r0 = res[(0 * L + i) * n:(0 * L + i + 1) * n].astype(object)
+            r1 = res[(1 * L + i) * n:(1 * L + i + 1) * n].astype(object)
+            lhs = (r0 + r1 * self.ntt(self.s_old, i) - self.t[i * n:(i + 1) * n].astype(object) * self.ntt(self.s_new, i)) % qs[i]
+            diff = self.intt(lhs, i)
+            centered = np.array([int(v) if v <= qs[i] // 2 else int(v) - qs[i] for v in diff], dtype=object)
+            noises.append(centered)
+            assert max(abs(int(v)) for v in centered) < 1 << noise_bits, "keyswitch noise too large in limb %d" % i
+        for i in range(1, L):
+            assert (noises[i] == noises[0]).all(), "limbs disagree on the noise polynomial"

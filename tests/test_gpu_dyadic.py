@@ -59,3 +59,32 @@ def test_arbitrary_64bit_operands(hx, ctx, dev, orc):
     a = rng.integers(0, 2**64 - 1, size=2 * nm * n, dtype=np.uint64)
     b = rng.integers(0, 2**64 - 1, size=2 * nm * n, dtype=np.uint64)
     assert np.array_equal(gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm), orc.dyadic(a, b, n, mod, exact=True))
+
+
+def test_full_baseline_config3(hx, ctx, dev, orc):
+    """BASELINE config 3 at full size: n = 8192, 4 RNS moduli (GeneratePrimes(4, 52, 8192)), batch 4096 ciphertext pairs
+    generated on the device. Spot items against the oracle, every output word below its modulus, and the symmetric
+    components agree when the operands are swapped (out0, out2 unchanged; out1 unchanged)."""
+    import torch
+    n, nm, batch = 8192, 4, 4096
+    mod1 = np.array(orc.primes(nm, 52, n), dtype=np.uint64)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    a = torch.empty((batch, 2, nm, n), dtype=torch.int64, device=dev)
+    b = torch.empty((batch, 2, nm, n), dtype=torch.int64, device=dev)
+    for m in range(nm):
+        a[:, :, m].random_(0, int(mod1[m]), generator=g)
+        b[:, :, m].random_(0, int(mod1[m]), generator=g)
+    mod = hx.as_i64(np.tile(mod1, batch)).to(dev)
+    out = torch.empty((batch, 3, nm, n), dtype=torch.int64, device=dev)
+    ctx.dyadic_multiply(out.reshape(-1), a.reshape(-1), b.reshape(-1), mod, n, nm)
+    ctx.sync()
+    for k in (0, 1, 2047, 4095):
+        want = orc.dyadic(hx.to_u64(a[k]).reshape(-1).copy(), hx.to_u64(b[k]).reshape(-1).copy(), n, mod1, exact=True)
+        assert np.array_equal(hx.to_u64(out[k]).reshape(-1), want), f"item {k}"
+    q = torch.tensor([int(v) for v in mod1], dtype=torch.int64, device=dev).view(1, 1, nm, 1)
+    assert bool(((out >= 0) & (out < q)).all())
+    out2 = torch.empty_like(out)
+    ctx.dyadic_multiply(out2.reshape(-1), b.reshape(-1), a.reshape(-1), mod, n, nm)
+    ctx.sync()
+    assert torch.equal(out, out2)

@@ -163,3 +163,81 @@ def test_repeated_launches_are_bit_identical(hx, ctx, dev, orc):
         else:
             assert torch.equal(ref, d_r)
     plan.close()
+
+
+def test_golden_digests(hx, ctx, dev, orc):
+    """the committed digests of the BASELINE shapes (tests/golden/ks_golden.json) straight from the GPU, through both
+    pipelines: one launch of the two instances (small-batch kernels) and the two instances inside a batch of 160
+    (slot-major pipeline for N = 16384)"""
+    import json
+    from pathlib import Path
+    gold = json.loads((Path(__file__).parent / "golden" / "ks_golden.json").read_text())
+    by_shape = {}
+    for v in gold["vectors"]:
+        by_shape.setdefault((v["n"], v["L"], v["K"], v["bits"]), []).append(v)
+    for (n, L, K, bits), vs in by_shape.items():
+        case = KsCase(orc, n, L, K, seed=n + L, bits=bits)
+        ts, rs = zip(*[case.inputs(orc, v["instance"]) for v in vs])
+        for nb in (len(vs), 160):
+            tt = [ts[b % len(vs)] for b in range(nb)]
+            rr = [rs[b % len(vs)] for b in range(nb)]
+            got = run_gpu(hx, ctx, dev, case, tt, rr)
+            for b in (0, 1, nb - 2, nb - 1):
+                v = vs[b % len(vs)]
+                assert f"{orc.fnv(got[b]):016x}" == v["fnv_result_out"], (n, L, K, bits, nb, b)
+
+
+def test_rlwe_at_baseline_size(hx, ctx, dev, orc):
+    """N = 16384, decomp 6 / 7 key moduli, 51-bit primes, REAL switching keys: the GPU output decrypts under the old key to
+    t * s_new up to small noise, identically in every limb (what the reference's SEAL bridge test asserts,
+    experimental/bridge-seal/tests/keyswitch-example.cpp:119-206) -- and equals the oracle bit for bit"""
+    from ks_util import RlweCase
+    n, L, K = 16384, 6, 7
+    rc = RlweCase(orc, n, L, K, 51)
+    zeros = np.zeros(2 * L * n, dtype=np.uint64)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, L + 1, 2, rc.moduli, rc.modswitch)
+    plan.set_keys(rc.keys)
+    for nb in (1, 96):                                            # small-batch kernels, slot-major pipeline
+        d_t = hx.as_i64(np.tile(rc.t, nb)).to(dev)
+        d_r = hx.as_i64(np.tile(zeros, nb)).to(dev)
+        plan.keyswitch(d_r, d_t, nb)
+        ctx.sync()
+        out = hx.to_u64(d_r).reshape(nb, -1)
+        rc.check(out[0])
+        assert (out == out[0]).all()
+    want = zeros.copy()
+    orc.keyswitch(want, rc.t, n, L, K, L + 1, rc.moduli, rc.keys, rc.modswitch)
+    assert np.array_equal(out[0], want)
+    plan.close()
+
+
+def test_full_baseline_batch_properties(hx, ctx, dev, orc):
+    """BASELINE config 4 at full size: N = 16384, decomp 7, batch 1024 of independent random ciphertexts generated on the
+    device. Spot instances (first, both sides of a scratch-chunk boundary, last) against the oracle; every output word in
+    range; a second launch on the same inputs adds exactly the same amount (additivity in `result`)."""
+    import torch
+    n, L, K, nb = 16384, 7, 8, 1024
+    case = KsCase(orc, n, L, K, seed=4)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    t = torch.empty((nb, L, n), dtype=torch.int64, device=dev)
+    r = torch.empty((nb, 2, L, n), dtype=torch.int64, device=dev)
+    for i in range(L):
+        t[:, i].random_(0, int(case.moduli[i]), generator=g)
+        r[:, :, i].random_(0, int(case.moduli[i]), generator=g)
+    r0 = r.clone()
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    plan.keyswitch(r.reshape(-1), t.reshape(-1), nb)
+    ctx.sync()
+    for b in (0, 255, 256, 1023):
+        want = case.expected(orc, hx.to_u64(t[b]).reshape(-1).copy(), hx.to_u64(r0[b]).reshape(-1).copy())
+        assert np.array_equal(hx.to_u64(r[b]).reshape(-1), want), f"instance {b}"
+    q = torch.tensor([int(v) for v in case.moduli[:L]], dtype=torch.int64, device=dev).view(1, 1, L, 1)
+    assert bool(((r >= 0) & (r < q)).all()), "output word out of range"
+    delta = (r - r0) % q
+    r1 = r.clone()
+    plan.keyswitch(r1.reshape(-1), t.reshape(-1), nb)
+    ctx.sync()
+    assert torch.equal((r1 - r) % q, delta), "second launch added a different amount"
+    plan.close()

@@ -24,12 +24,22 @@ print("# SQ_* cycle counters are in quad-cycles (MI355X_MICROARCH.md); FETCH_SIZ
 print("# fetch_x2 applies the gfx950 correction (FETCH_SIZE reports 1/2 of wide coalesced reads)")
 names = sorted(vals, key=lambda k: -sum(dur.get(k, [0])))
 ks_bytes = 0.0
+ks_valu = 0.0
+clk_num = clk_den = 0.0
 for k in names:
     v = vals[k]
     d = sum(dur[k]) / len(dur[k])
     print(f"\n{k}   avg duration under PMC {d:.1f} us")
     for c in sorted(v):
         print(f"    {c:24s} {v[c]:.6g}")
+    if k.startswith("k_ks") and "SQ_INSTS_VALU" in v:
+        ks_valu += v["SQ_INSTS_VALU"]
+    if "GRBM_GUI_ACTIVE" in v:
+        # effective shader clock under this kernel = busy cycles / duration (MI355X_MICROARCH.md, DVFS)
+        # (the counter is summed over the 8 XCDs)
+        print("    -> shader clock while it ran: %.2f GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)" % (v["GRBM_GUI_ACTIVE"] / 8 / (d * 1e3)))
+        if k.startswith("k_ks"):
+            clk_num += v["GRBM_GUI_ACTIVE"] / 8; clk_den += d * 1e3
     if "SQ_WAVE_CYCLES" in v:
         wc = v["SQ_WAVE_CYCLES"]
         print("    -> wave time split: active %.1f%%  issue-stall %.1f%%  waitcnt/barrier %.1f%%" % (
@@ -44,6 +54,12 @@ for k in names:
 alg = (L + 4 * L) * 16384 * 8
 print(f"\n# keyswitch pipeline: measured HBM-side traffic {ks_bytes / batch / 1e6:.2f} MB per keyswitch "
       f"vs algorithmic {alg / 1e6:.2f} MB  (ratio {ks_bytes / batch / alg:.2f})")
+clk = clk_num / clk_den if clk_den else 2.0
+print(f"# keyswitch pipeline: {ks_valu / batch:.0f} VALU wave-instructions per keyswitch; at 4 cycles each on 1024 SIMDs and "
+      f"{clk:.2f} GHz that is {ks_valu / batch * 4 / 1024 / (clk * 1e3):.2f} us of FP64 issue per keyswitch")
+json.dump({"valu_wave_instructions_per_keyswitch": ks_valu / batch, "shader_clock_ghz": clk, "batch": batch, "L": L,
+           "note": "sum of SQ_INSTS_VALU over the keyswitch kernels of one chunk / batch; clock = GRBM_GUI_ACTIVE / 8 XCDs / duration"},
+          open(f"{root}/alu.json", "w"))
 json.dump({"keyswitch_traffic_bytes_per_unit": ks_bytes / batch, "batch": batch, "L": L, "alg_bytes_per_unit": alg,
            "note": "sum over the five keyswitch kernels of 2*FETCH_SIZE + WRITE_SIZE (KiB->B), per keyswitch"},
           open(f"{root}/traffic.json", "w"))
