@@ -21,10 +21,12 @@ using namespace hx;
 // butterflies whenever a precondition fails, so every input still gets the reference's exact answer.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q, u32 n,
-                              double* __restrict__ w, double* __restrict__ wp, u32* __restrict__ violations) {
+                              double* __restrict__ w, double* __restrict__ wp, u32* __restrict__ violations,
+                              u32* __restrict__ zero_for_later) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (i == 0) { w[0] = 0.0; wp[0] = 0.0; return; }          // index 0 is never read by either transform
+    // index 0 is never read by either transform; its thread resets the counter a launch 32 launches from now will use
+    if (i == 0) { w[0] = 0.0; wp[0] = 0.0; *zero_for_later = 0; return; }
     const u64 r = roots[i], p = precon[i];
     // 128-bit  D = r*2^64 - p*q  must satisfy 0 <= D < q
     const u64 lo = p * q, hi = mulhi(p, q);
@@ -135,6 +137,111 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
     }
 }
 
+// Persistent variants (the default fast path): one workgroup per CU walks the batch, and the NEXT polynomial's words
+// are requested into 2 E spare registers at the very start of the current transform. A lone 1024-thread workgroup per
+// CU otherwise waits ~5 us for its 128 KiB input before every ~13 us transform (tools/ntt_timeline.hip) and pays the
+// dispatch gap between workgroups. Vector memory returns in order, so the request must sit where nothing else is
+// waited for until it has landed: the first two passes take their twiddles through the scalar cache (~14 k cycles).
+// (Requested after the cross-wave re-deal instead, the first per-lane twiddle wait stalls on it:
+// tools/experiments/persistent_prefetch.patch measured that 10 % SLOWER.)
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restrict__ x, const u64* __restrict__ roots,
+                                                                  const u64* __restrict__ precon, u64 q,
+                                                                  const double* __restrict__ w,
+                                                                  const double* __restrict__ wp,
+                                                                  const u32* __restrict__ violations, u32 batch) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
+    const Mod m{(double)q, 1.0 / (double)q};
+    const bool bad_tables = *violations != 0;
+    u64 raw[G::E];
+    {
+        const int tid = threadIdx.x;
+        const u64* p0 = x + size_t(blockIdx.x) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
+    }
+#pragma unroll 1
+    for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u64* px = x + size_t(p) * G::N;
+        bool out_of_range = false;
+        double f[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            out_of_range |= raw[r] >= limit;
+            f[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
+        }
+        const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;                // (last round: a harmless re-read)
+        const u64* pnx = x + size_t(pn) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
+        WgNttF64<LOGN, LOGE, LAZY>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        const bool slow = __syncthreads_or(out_of_range) || bad_tables;          // see k_ntt_fwd_x
+        if (!slow) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+        } else {
+            slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
+            __syncthreads();
+        }
+    }
+}
+
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restrict__ x, const u64* __restrict__ iroots,
+                                                                  const u64* __restrict__ iprecon, u64 q, u64 inv_n,
+                                                                  u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p,
+                                                                  const double* __restrict__ w,
+                                                                  const double* __restrict__ wp, hxf::InvScale sc,
+                                                                  const u32* __restrict__ violations, u32 batch) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
+    const Mod m{(double)q, 1.0 / (double)q};
+    const bool bad_tables = *violations != 0;
+    u64 raw[G::E];
+    {
+        const int tid = threadIdx.x;
+        const u64* p0 = x + size_t(blockIdx.x) * G::N;
+        const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
+    }
+#pragma unroll 1
+    for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u64* px = x + size_t(p) * G::N;
+        bool out_of_range = false;
+        double f[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            out_of_range |= raw[r] >= limit;
+            f[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
+        }
+        // the inverse starts with its per-lane twiddle pass: the next input is requested behind that pass's twiddles,
+        // i.e. after the first (wave-private) re-deal -- the following passes use the scalar cache
+        const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;
+        const u64* pnx = x + size_t(pn) * G::N;
+        const u32 tB = u32(G::idxB(0, tid));
+        WgNttF64<LOGN, LOGE, LAZY>::template inverse<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, [&] {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
+        });
+        const bool slow = __syncthreads_or(out_of_range) || bad_tables;
+        if (!slow) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+        } else {
+            slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+            __syncthreads();
+        }
+    }
+}
+
 static bool fast_path_enabled() {
     static const bool v = [] { const char* e = getenv("HEXL_NTT_INT"); return !(e && atoi(e) == 1); }();
     return v;
@@ -143,15 +250,20 @@ static bool fast_path_enabled() {
 // device scratch for the derived tables: [w | w/p] (n doubles each) + the violation counter
 static int prepare_tables(hexl_ctx* ctx, const u64* roots, const u64* precon, u64 q, u64 n, double** w, double** wp,
                           u32** viol) {
-    const size_t bytes = 2 * n * sizeof(double) + 256;
+    // layout: 64 violation counters (one per launch, round robin: no memset per launch -- each launch's prepare kernel
+    // zeroes the counter 32 launches ahead, long after its last reader has finished on this stream), then w, w/p
+    const size_t bytes = 256 + 2 * n * sizeof(double);
+    const void* before = ctx->d_ntt_tab;
     int rc = hx_reserve_device(ctx, &ctx->d_ntt_tab, &ctx->d_ntt_tab_bytes, bytes);
     if (rc) return rc;
-    *w = (double*)ctx->d_ntt_tab;
+    if (ctx->d_ntt_tab != before) HX_CHECK(hipMemsetAsync(ctx->d_ntt_tab, 0, 256, ctx->stream));
+    u32* counters = (u32*)ctx->d_ntt_tab;
+    *w = (double*)((char*)ctx->d_ntt_tab + 256);
     *wp = *w + n;
-    *viol = (u32*)(*wp + n);
-    HX_CHECK(hipMemsetAsync(*viol, 0, sizeof(u32), ctx->stream));
+    const u32 seq = ctx->ntt_seq++;
+    *viol = counters + (seq & 63);
     hipLaunchKernelGGL(k_ntt_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, roots, precon, q,
-                       (u32)n, *w, *wp, *viol);
+                       (u32)n, *w, *wp, *viol, counters + ((seq + 32) & 63));
     return (int)hipGetLastError();
 }
 
@@ -253,6 +365,21 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
             return 0;
         }))
         return rc;
+    // persistent workgroups with input prefetch wherever 2 E more registers fit (not N = 32768: 64 data registers at
+    // 1024 threads) and the batch fills the chip more than once; HEXL_NTT_PERSIST=0 keeps one workgroup per polynomial
+    static const int persist = [] { const char* e = getenv("HEXL_NTT_PERSIST"); return e ? atoi(e) : 1; }();
+    const size_t slots = size_t(ctx->num_cu) * (G::LDS_USED > 80 * 1024 ? 1 : (160 * 1024) / G::LDS_USED);
+    if (persist && !G::HALF_ONLY && batch > slots) {
+        static PerDeviceOnce once_p;
+        if (int rc = once_p.run(ctx->device, [] {
+                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+                return 0;
+            }))
+            return rc;
+        hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x,
+                           roots, precon, q, w, wp, viol, (u32)batch);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, w, wp, viol, (u32)batch);
     return (int)hipGetLastError();
@@ -268,6 +395,19 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
             return 0;
         }))
         return rc;
+    static const int persist = [] { const char* e = getenv("HEXL_NTT_PERSIST"); return e ? atoi(e) : 1; }();
+    const size_t slots = size_t(ctx->num_cu) * (G::LDS_USED > 80 * 1024 ? 1 : (160 * 1024) / G::LDS_USED);
+    if (persist && !G::HALF_ONLY && batch > slots) {
+        static PerDeviceOnce once_p;
+        if (int rc = once_p.run(ctx->device, [] {
+                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+                return 0;
+            }))
+            return rc;
+        hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x,
+                           ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
     return (int)hipGetLastError();

@@ -188,23 +188,31 @@ struct WgNttF64 {
             inv_first<GRP + 1>(v, tid, iw, iwp, m, sc);
         }
     }
-    template <int PASS, bool FRESH = false>
+    // `before_uniform` runs once, right after the re-deal that precedes the first pass whose twiddles are wave-uniform
+    // (scalar loads): from there on the transform waits for no vector load, so a long-latency request issued there
+    // (a persistent kernel's next input) delays nothing -- vector memory returns in order.
+    template <int PASS>
+    static constexpr bool inv_pass_uniform = (PASS == G::P - 2) || (G::KL + PASS * LOGE >= 6);
+    template <int PASS, bool FRESH = false, class Hook = NoHook>
     __device__ static __forceinline__ void inv_pass(double (&v)[E], double* lds, int tid, const double* iw,
-                                                    const double* iwp, const Mod m, const InvScale sc) {
+                                                    const double* iwp, const Mod m, const InvScale sc,
+                                                    Hook before_uniform = Hook()) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
             constexpr bool LEAD = !(FRESH && PASS == 0);
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
+            if constexpr (inv_pass_uniform<PASS> && (PASS == 0 || !inv_pass_uniform<(PASS > 0 ? PASS - 1 : 0)>)) before_uniform();
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF>(v, Gp, iw, iwp, m, sc);
-            inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc);
+            inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc, before_uniform);
         }
     }
-    template <bool FRESH = false>
+    template <bool FRESH = false, class Hook = NoHook>
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
-                                                   const double* iwp, const Mod m, const InvScale sc) {
+                                                   const double* iwp, const Mod m, const InvScale sc,
+                                                   Hook before_uniform = Hook()) {
         inv_first<0>(v, tid, iw, iwp, m, sc);
-        inv_pass<0, FRESH>(v, lds, tid, iw, iwp, m, sc);
+        inv_pass<0, FRESH>(v, lds, tid, iw, iwp, m, sc, before_uniform);
     }
 };
 
