@@ -48,6 +48,7 @@ C_ABI = {
     "hexl_ks_plan_destroy": [_vp],
     "hexl_ks_set_keys": [_vp, ctypes.POINTER(_vp)],
     "hexl_keyswitch": [_vp, _vp, _vp, _sz],
+    "hexl_multiply_relinearize": [_vp, _vp, _vp, _vp, _sz],
     "hexl_ks_scratch_bytes": [_vp, _sz],
     "hexl_ntt_fwd_host": [_vp, ctypes.POINTER(_vp), _sz, _vp, _vp, _u64, _u64],
     "hexl_ntt_inv_host": [_vp, ctypes.POINTER(_vp), _sz, _vp, _vp, _u64, _u64, _u64, _u64],
@@ -190,6 +191,10 @@ class KeySwitchPlan:
 
     def keyswitch(self, result, t_target, batch: int):
         _check(lib().hexl_keyswitch(self.h, _ptr(result), _ptr(t_target), batch), "hexl_keyswitch")
+
+    def multiply_relinearize(self, out, a, b, batch: int):
+        """out[batch][2][L][n] = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), one fused pass (N = 16384)"""
+        _check(lib().hexl_multiply_relinearize(self.h, _ptr(out), _ptr(a), _ptr(b), batch), "hexl_multiply_relinearize")
 
     def keyswitch_host(self, results, t_targets):
         n = len(results)

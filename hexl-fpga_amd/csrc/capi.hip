@@ -321,6 +321,13 @@ extern "C" int hexl_keyswitch(hexl_ks_plan* p, uint64_t* d_result, const uint64_
     return hx_launch_keyswitch(p, d_result, d_t_target, batch, 7, nullptr);
 }
 
+extern "C" int hexl_multiply_relinearize(hexl_ks_plan* p, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b,
+                                         size_t batch) {
+    if (!p || !d_out || !d_a || !d_b) return HEXL_E_BADARG;
+    HX_CHECK(hipSetDevice(p->ctx->device));
+    return hx_launch_multiply_relinearize(p, d_out, d_a, d_b, batch);
+}
+
 extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const uint64_t* d_t_target, size_t batch,
                                    int iters, float* ms_out) {
     if (!p || !ms_out || iters <= 0) return HEXL_E_BADARG;

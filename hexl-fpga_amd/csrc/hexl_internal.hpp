@@ -127,6 +127,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan*, u64* d_result, const u64* d_t_target,
 int hx_launch_keyswitch_x(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
                           hipEvent_t* ev);
 bool hx_ks_x_applies(const hexl_ks_plan*, size_t nb);
+int hx_launch_multiply_relinearize(hexl_ks_plan*, u64* d_out, const u64* d_a, const u64* d_b, size_t batch);
 u32 hx_ks_x_loge();
 // index of coefficient held in register r of thread tid after a forward transform ("B layout")
 u32 hx_idxB(u32 logn, u32 r, u32 tid);

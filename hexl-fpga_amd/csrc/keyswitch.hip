@@ -289,3 +289,29 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     }
     return 0;
 }
+
+// fused ciphertext multiply + relinearize (the use-case of the reference's combined image,
+// device/dyadic_multiply_keyswitch.cpp:4-5): chunks of the batch through the slot-major pipeline on the caller's stream
+int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t nb);
+int hx_launch_multiply_relinearize(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t batch) {
+    if (!batch) return 0;
+    if (!p->have_keys) return HEXL_E_NOKEYS;
+    if (!p->use_f64 || p->logn != 14) return HEXL_E_BADARG;
+    const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    const size_t lane_words = chunk * scratch_words(p) * p->n;
+    if (p->cap < chunk) {
+        if (p->d_scratch) { HX_CHECK(hipDeviceSynchronize()); HX_CHECK(hipFree(p->d_scratch)); }
+        p->d_scratch = nullptr; p->cap = 0;
+        HX_CHECK(hipMalloc((void**)&p->d_scratch, 2 * lane_words * sizeof(u64)));
+        p->cap = chunk;
+    }
+    p->cur = p->ctx->stream;
+    p->cur_scratch = p->d_scratch;
+    const size_t per = 2 * p->L * p->n;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        int rc = hx_launch_mulrelin_x(p, d_out + b0 * per, d_a + b0 * per, d_b + b0 * per, nb);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -47,6 +47,9 @@ struct KsArgsX {
     const u64* t_target;     // [chunk][L][n]
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
+    // fused multiply + relinearize (hexl_multiply_relinearize): ciphertext pairs a, b [chunk][2][L][n]; the keyswitch input
+    // is a_1 . b_1 (never stored) and `result` is WRITTEN with (a_0 b_0, a_0 b_1 + a_1 b_0) + keyswitch(a_1 b_1)
+    const u64 *mul_a, *mul_b;
     unsigned long long* stamps;   // tools/ksx_timeline.hip only (KX_TIMELINE builds): [workgroup][wave][KX_NST]
 };
 
@@ -111,6 +114,19 @@ __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* 
 // its register receives word r of the NEXT round's input (`next`, A order; never null), so that input crosses
 // the memory system during this multiply-accumulate instead of stalling the next transform. A scheduling barrier per
 // coefficient keeps the compiler from hoisting the whole stream to the top (and spilling what it displaced).
+// (x . y) mod p of two natural-order limbs as centred doubles in B register order (fused multiply + relinearize; direct
+// B-order loads, 16-coefficient geometry only). In-range operands: |x|, |y| <= p/2 after centring, |x.y mod p| <= 0.7p.
+template <class G>
+__device__ __forceinline__ void load_product_to_B(double (&v)[G::E], const u64* __restrict__ x, const u64* __restrict__ y,
+                                                  int tid, const Mod m) {
+    static_assert(G::KL <= 2, "fused multiply + relinearize uses the 16-coefficient geometry");
+    const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+    for (int r = 0; r < G::E; ++r)
+        v[r] = hxf::reduce(hxf::mul_mod(hxf::reduce(hxf::to_f64((x + G::idxB(r, 0))[tB]), m),
+                                        hxf::reduce(hxf::to_f64((y + G::idxB(r, 0))[tB]), m), m), m);
+}
+
 // position of register r / thread tid in a natural-order array about to enter an INVERSE transform (B order): direct
 // for small lane runs, A order (then re-dealt through LDS) otherwise -- see load_natural_to_B
 template <class G>
@@ -163,7 +179,7 @@ __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __re
 // (Kept out of k_ksx_special: an inverse transform beside the 64 accumulator registers made the allocator spill a few
 // accumulators, and every reload inside the multiply-accumulate waits for the whole key prefetch queue -- vector
 // memory returns in order. That version spent 42 k cycles per multiply-accumulate instead of 10 k.)
-template <int LOGN, int LOGE, int LAZY>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, 0>;
@@ -179,7 +195,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         double v[G::E];
-        load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m);
+        if constexpr (FUSED) {                                    // t_target[d] = a_1[d] . b_1[d]
+            const size_t at = ((size_t(item / a.L) * 2 + 1) * a.L + d) * G::N;
+            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, md.m);
+        } else {
+            load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m);
+        }
         W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         double* cd = a.c + size_t(item) * G::N;
 #pragma unroll
@@ -248,15 +269,36 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
 
 // ---- decomposition slots: steps 2-3 and 5-7 for one (instance, limb) ----------------------------------------------
 // steps 5-7 for one k: w = NTT((s'_k + fix_i) mod q_i) from the raw s'_k words in v (A order); result[k][i] += (acc - w) * msf_i
-template <class G, class W>
+// FUSED (k = 0, 1): the "old result" is component k of the ciphertext product, formed here from the operand limbs
+// (a0, a1, b0, b1 of this limb, natural order): k = 0: a0 b0; k = 1: a0 b1 + a1 b0; `res` is written, not accumulated into
+template <class G, class W, int FUSED_K = -1>
 __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
-                                               double* lds, int tid, const double* tb, const KsModF64& md) {
+                                               double* lds, int tid, const double* tb, const KsModF64& md,
+                                               const u64* a0 = nullptr, const u64* a1 = nullptr, const u64* b0 = nullptr,
+                                               const u64* b1 = nullptr) {
     const Mod m = md.m;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r] + md.fix, m);             // intt2_redu.hpp:49-51
     W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);               // |w| <= 2.14p: |prod - w| <= 2.64p
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
+    if constexpr (FUSED_K >= 0) {
+        static_assert(G::KL <= 2, "fused multiply + relinearize uses the 16-coefficient geometry");
+        const u32 tB = u32(G::idxB(0, tid));
+        auto ld = [&](const u64* p, int r) { return hxf::reduce(hxf::to_f64((p + G::idxB(r, 0))[tB]), m); };
+#pragma unroll
+        for (int r0 = 0; r0 < G::E; r0 += 4) {                    // four coefficients at a time: 8 or 16 loads in flight
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r) {
+                double old;
+                if constexpr (FUSED_K == 0) old = hxf::mul_mod(ld(a0, r), ld(b0, r), m);
+                else old = hxf::reduce(hxf::mul_mod(ld(a0, r), ld(b1, r), m) + hxf::mul_mod(ld(a1, r), ld(b0, r), m), m);
+                (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(hxf::reduce(old + v[r], m), m));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     if constexpr (G::KL <= 2) {
         // read-modify-write at the B positions, half of the registers at a time (a full register copy of the old words
         // does not fit beside the accumulators)
@@ -299,7 +341,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     for (int r = 0; r < G::E; ++r) (res + G::idxA(r, 0))[u32(tid)] = hxf::from_f64(atA[G::pad(G::idxA(r, 0))]);
 }
 
-template <int LOGN, int LOGE, int LAZY>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
@@ -331,7 +373,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         KX_STAMP(60);
-        load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
+        if constexpr (FUSED) {
+            const size_t at = ((size_t(b) * 2 + 1) * L + i) * G::N;
+            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, m);
+        } else {
+            load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
+        }
         KX_STAMP(61);
         const double* k0 = a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N;
         mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, round_src(first), tid, m);
@@ -364,7 +411,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         KX_STAMP(4 * L + 0);
-        ksx_down_round<G, W>(v, acc0, a.result + ((size_t(b) * 2 + 0) * L + i) * G::N, ldsx, tid, tb, md);
+        const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * G::N;
+        if constexpr (FUSED) ksx_down_round<G, W, 0>(v, acc0, a.result + o0, ldsx, tid, tb, md, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
+        else ksx_down_round<G, W>(v, acc0, a.result + o0, ldsx, tid, tb, md);
         const double* nxt = a.s + (size_t(b) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -376,7 +425,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
         u32 toff = i * 4 * G::N;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        ksx_down_round<G, W>(v, acc1, a.result + ((size_t(b) * 2 + 1) * L + i) * G::N, ldsx, tid, tb, md);
+        const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * G::N;
+        if constexpr (FUSED) ksx_down_round<G, W, 1>(v, acc1, a.result + o1, ldsx, tid, tb, md, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
+        else ksx_down_round<G, W>(v, acc1, a.result + o1, ldsx, tid, tb, md);
         KX_STAMP(4 * L + 8);
     }
     }
@@ -389,14 +440,14 @@ static int set_lds_x(K kern, size_t bytes) {
     return 0;
 }
 
-template <int LOGN, int LOGE, int LAZY>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
             int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY>, G::LDS_USED);
-            if (!rc) rc = set_lds_x(k_ksx_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
-            if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksx_intt<LOGN, LOGE, LAZY, FUSED>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED>, G::LDS_USED);
             return rc;
         }))
         return rc0;
@@ -411,13 +462,13 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
         return dim3(8 * (persist && per_xcd > cu_per_xcd ? cu_per_xcd : per_xcd));
     };
     if (stage_mask & 1)
-        hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY>), grid_for(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY, FUSED>), grid_for(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2)
         hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }
@@ -445,6 +496,7 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.s = a.c + p->cap * L * n;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    a.mul_a = a.mul_b = nullptr;
     a.stamps = nullptr;
     if (p->logn != 14) return HEXL_E_BADARG;
     // LAZY template argument = forward reduction period of the transforms (f64_arith.hpp), as in keyswitch_f64.hip
@@ -456,4 +508,20 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
         case 3:  return run_chunk_x<14, 4, 3>(p, a, stage_mask, ev);
         default: return run_chunk_x<14, 4, 0>(p, a, stage_mask, ev);
     }
+}
+
+// fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry)
+int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t nb) {
+    const size_t n = p->n, L = p->L;
+    if (p->logn != 14 || !p->use_f64 || !p->d_keys_x || p->x_loge != 4) return HEXL_E_BADARG;
+    KsArgsX a;
+    a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_x;
+    a.c = (double*)p->cur_scratch;
+    a.s = a.c + p->cap * L * n;
+    a.t_target = nullptr; a.result = d_out;
+    a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    a.mul_a = d_a; a.mul_b = d_b;
+    a.stamps = nullptr;
+    // (moduli small enough for the longer lazy periods run with period 3 here: always valid, two fewer kernel variants)
+    return p->f64_lazy ? run_chunk_x<14, 4, 3, true>(p, a, 7, nullptr) : run_chunk_x<14, 4, 0, true>(p, a, 7, nullptr);
 }

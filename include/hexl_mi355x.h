@@ -92,6 +92,14 @@ int hexl_ks_set_keys(hexl_ks_plan* plan, const uint64_t* const* h_keys);
  * device/keyswitch/ (SURVEY 2.1-K4). */
 int hexl_keyswitch(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_target,
                    size_t batch);
+/* Beyond the reference's envelope (the use-case of its combined image,
+ * device/dyadic_multiply_keyswitch.cpp:4-5): ciphertext multiply + relinearize in one pass.
+ *   d_a, d_b [batch][2][L][n] (the DyadicMultiply operand layout with n_moduli = L, words < q_i);
+ *   d_out    [batch][2][L][n] is WRITTEN with (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), i.e. what
+ *   DyadicMultiply followed by KeySwitch(result = components 0..1, t_target = component 2) leaves -- but the
+ *   three-component product never exists in memory. n = 16384 and moduli < 2^52 only (else HEXL_E_BADARG). */
+int hexl_multiply_relinearize(hexl_ks_plan* plan, uint64_t* d_out, const uint64_t* d_a,
+                              const uint64_t* d_b, size_t batch);
 /* bytes of HBM scratch a batch of `batch` keyswitches needs (for capacity planning) */
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* plan, size_t batch);
 

@@ -1,0 +1,59 @@
+"""GPU parity: hexl_multiply_relinearize (ciphertext multiply + relinearize in one pass, SURVEY 8f.4 -- the use-case of
+the reference's combined image, device/dyadic_multiply_keyswitch.cpp:4-5) against the COMPOSITION of the two oracle
+calls the reference's flow makes: DyadicMultiply (tests/test_dyadic_multiply.cpp:59-82 semantics), then KeySwitch with
+result = product components 0..1 and t_target = component 2 (tests/test_dyadic_multiply_keyswitch.cpp:295-313 runs the
+two primitives of that image back to back)."""
+import numpy as np
+import pytest
+
+from ks_util import KsCase, primes_below
+
+pytestmark = pytest.mark.gpu
+
+
+def operands(orc, case, b, which):
+    n, L = case.n, case.L
+    return np.concatenate([orc.splitmix(n, case.seed * 7 + b * 131 + which * 17 + p * 5 + i, int(case.moduli[i]))
+                           for p in range(2) for i in range(L)])
+
+
+def composed(orc, case, a, b):
+    n, L = case.n, case.L
+    prod = orc.dyadic(a, b, n, case.moduli[:L], exact=True)              # [3][L][n]
+    out = prod[:2 * L * n].copy()
+    orc.keyswitch(out, prod[2 * L * n:].copy(), n, L, case.K, L + 1, case.moduli, case.keys, case.modswitch)
+    return out
+
+
+@pytest.mark.parametrize("L,K,nb,strict", [(6, 7, 2, False), (7, 8, 96, False), (3, 4, 5, True)])
+def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, L, K, nb, strict):
+    n = 16384
+    moduli = primes_below(orc, K, 1 << 52, n) if strict else None      # just below 2^52: the strict FP64 kernels
+    case = KsCase(orc, n, L, K, seed=40 + L, moduli=moduli)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    distinct = min(nb, 3)
+    A = [operands(orc, case, b, 0) for b in range(distinct)]
+    B = [operands(orc, case, b, 1) for b in range(distinct)]
+    d_a = hx.as_i64(np.concatenate([A[b % distinct] for b in range(nb)])).to(dev)
+    d_b = hx.as_i64(np.concatenate([B[b % distinct] for b in range(nb)])).to(dev)
+    import torch
+    d_out = torch.full((nb * 2 * L * n,), -1, dtype=torch.int64, device=dev)   # written, not accumulated into
+    plan.multiply_relinearize(d_out, d_a, d_b, nb)
+    ctx.sync()
+    out = hx.to_u64(d_out).reshape(nb, -1)
+    want = [composed(orc, case, A[b], B[b]) for b in range(distinct)]
+    for b in range(nb):
+        assert np.array_equal(out[b], want[b % distinct]), f"instance {b}"
+    plan.close()
+
+
+def test_rejects_what_it_does_not_cover(hx, ctx, dev, orc):
+    case = KsCase(orc, 4096, 2, 3, seed=1)
+    plan = hx.KeySwitchPlan(ctx, 4096, 2, 3, 3, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    import torch
+    z = torch.zeros(2 * 2 * 4096, dtype=torch.int64, device=dev)
+    with pytest.raises(hx.HexlError):
+        plan.multiply_relinearize(z, z, z, 1)
+    plan.close()
