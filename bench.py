@@ -278,6 +278,40 @@ def main():
                 pl.close()
                 return {"keyswitches_per_s": nbx / (ms * 1e-3), "batch": nbx,
                         "alg_GBps": ks_alg_bytes(N, Lx) * nbx / (ms * 1e-3) / 1e9}
+            # ciphertext multiply + relinearize: DyadicMultiply then KeySwitch as two primitives vs the fused pass
+            def mulrelin():
+                nbx = min(a.batch, 2048)
+                g = torch.Generator(device=dev)
+                g.manual_seed(5)
+                xa = torch.empty((nbx, 2, L, N), dtype=torch.int64, device=dev)
+                xb = torch.empty((nbx, 2, L, N), dtype=torch.int64, device=dev)
+                for i in range(L):
+                    xa[:, :, i].random_(0, int(case.moduli[i]), generator=g)
+                    xb[:, :, i].random_(0, int(case.moduli[i]), generator=g)
+                mod = hx.as_i64(np.tile(case.moduli[:L], nbx)).to(dev)
+                prod = torch.empty((nbx, 3, L, N), dtype=torch.int64, device=dev)
+                out = torch.empty((nbx, 2, L, N), dtype=torch.int64, device=dev)
+                tt = torch.empty((nbx, L, N), dtype=torch.int64, device=dev)
+
+                def two_calls():
+                    ctx.dyadic_multiply(prod.reshape(-1), xa.reshape(-1), xb.reshape(-1), mod, N, L)
+                    out.copy_(prod[:, :2]); tt.copy_(prod[:, 2])          # the caller's re-packing between the primitives
+                    plan.keyswitch(out.reshape(-1), tt.reshape(-1), nbx)
+
+                def fused():
+                    plan.multiply_relinearize(out.reshape(-1), xa.reshape(-1), xb.reshape(-1), nbx)
+                res = {}
+                for name, fn in (("dyadic_then_keyswitch", two_calls), ("fused", fused)):
+                    fn(); torch.cuda.synchronize()
+                    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    f0.record()
+                    for _ in range(3):
+                        fn()
+                    f1.record(); torch.cuda.synchronize()
+                    res[name + "_per_s"] = nbx / (f0.elapsed_time(f1) / 3 * 1e-3)
+                res["batch"] = nbx
+                return res
+            extra["multiply_relinearize_16384_L%d" % L] = mulrelin()
             # the reference-representable shape 16384_6_7_7_2 (decomp 6, 7 key moduli), 52-bit primes
             extra["keyswitch_16384_6_7_7_2"] = other_shape(6, 7)
             # the same shape with 48-bit primes (SEAL's default parameter sizes for N=16384): longer lazy-reduction period

@@ -3,24 +3,29 @@
 // workgroup that produced the transforms, as the reference's pipes do -- `u` (15 MB per keyswitch in the (b, d)-major
 // pipeline of keyswitch_f64.hip) and `prod` never exist in memory.
 //
-// One workgroup = 512 threads x 32 coefficients (Geom<14,5>: three register passes, two re-deals), 256 VGPRs per
-// thread: 64 hold the polynomial in flight, 128 the two accumulators (prod[k][slot], k = 0, 1), the rest is working
-// space. Two kernels per chunk of instances:
+// One workgroup = 1024 threads x 16 coefficients (Geom<14,4>, 128 VGPRs per thread): 32 registers hold the polynomial
+// in flight, 64 the two accumulators (prod[k][slot], k = 0, 1), the rest is working space. Three kernels per chunk:
 //
-//   k_ksx_special (b)       for every d:  c_d = INTT_{q_d}(t_target[d])  -> scratch (canonical doubles, natural order),
-//                                         acc_k += NTT_{q_sp}(c_d mod q_sp) . key[d][special][k]        (steps 1-3)
-//                           then          s'_k = INTT_{q_sp}(acc_k) + floor(q_sp/2)  -> scratch         (step 4)
-//   k_ksx_main (b, i < L)   for every d:  acc_k += NTT_{q_i}(c_d mod q_i) . key[d][i][k]   (d == i: t_target[i] itself)
-//                           then, k = 0, 1:  w = NTT_{q_i}((s'_k + fix_i) mod q_i);
-//                                            result[k][i] += (acc_k - w) . msf_i                        (steps 5-7)
+//   k_ksx_intt    (b, d)    c_d = INTT_{q_d}(t_target[d])  -> scratch (canonical doubles, natural order)       (step 1)
+//   k_ksx_special (b)       acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k]                       (steps 2-3)
+//                           s'_k = INTT_{q_sp}(acc_k) + floor(q_sp/2)  -> scratch                              (step 4)
+//   k_ksx_main    (b, i<L)  acc_k = sum_d NTT_{q_i}(c_d mod q_i) . key[d][i][k]   (d == i: t_target[i] itself)
+//                           k = 0, 1:  w = NTT_{q_i}((s'_k + fix_i) mod q_i);  result[k][i] += (acc_k - w) . msf_i  (steps 5-7)
 //
-// HBM-side traffic per keyswitch: t_target twice, c once out and (L2 permitting) once in, s', result in and out --
-// against t_target + 8 L^2 n of u both ways + prod both ways before. Arithmetic and bounds are those of f64_arith.hpp;
-// results are bit-identical to the (b, d)-major pipeline and the integer kernels.
+// HBM-side traffic per keyswitch (PMC, profiles/): 17.5 MB against 25.6 MB for the (b, d)-major pipeline and 4.6 MB
+// algorithmic. Arithmetic and bounds are those of f64_arith.hpp; results are bit-identical to the (b, d)-major
+// pipeline and the integer kernels.
 //
-// Natural-order arrays (t_target, result) meet the transforms' "B" register order through an LDS re-deal (A <-> B):
-// at 32 coefficients per thread a lane owns 16 adjacent words, and direct B-order global access would touch 64
-// cache lines per wave instruction.
+// What shaped the code (all measured on the MI355X, tools/ksx_timeline.hip; numbers in DESIGN.md 4.4):
+//  * REGISTERS. Everything lives or dies by keeping the 64 accumulator registers out of scratch: a spilled accumulator
+//    is reloaded inside the multiply-accumulate, and because vector memory returns in order that reload waits for the
+//    whole key prefetch queue -- 37-45 k cycles per multiply-accumulate instead of 10 k. Hence: straight-line phases
+//    instead of one loop with an up/down branch (128 phi nodes on the accumulators cost ~200 spills), the inverse
+//    transforms in their own kernel (two twiddle tables: 92 working registers), no persistent item loop around k_ksx_main.
+//  * 16 x 1024 beats 32 x 512 (256 VGPRs, two re-deals instead of three): with two waves per SIMD every exposed load
+//    latency is paid in full; HEXL_KSX_LOGE=5 still selects that geometry (its natural-order arrays then meet the
+//    transforms' "B" register order through an LDS re-deal: a lane owns 16 adjacent words there).
+//  * The NEXT round's input is requested inside the multiply-accumulate, into the registers the products free.
 #include <stdlib.h>
 
 #include "hexl_internal.hpp"
@@ -29,7 +34,7 @@
 using namespace hx;
 
 #ifndef KX_NEXT_MODE
-#define KX_NEXT_MODE 1
+#define KX_NEXT_MODE 0
 #endif
 #ifndef KX_TF
 #define KX_TF 0      // twiddle ring of the transforms (ntt_core_f64.hpp); 0 = off
@@ -114,6 +119,8 @@ __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* 
 // its register receives word r of the NEXT round's input (`next`, A order; never null), so that input crosses
 // the memory system during this multiply-accumulate instead of stalling the next transform. A scheduling barrier per
 // coefficient keeps the compiler from hoisting the whole stream to the top (and spilling what it displaced).
+// (KX_NEXT_MODE 1 requests the next input in one burst behind the last key instead: the same within noise at four
+// waves per SIMD, 10.4 k against 9.5 k cycles per multiply-accumulate in the timeline tool.)
 // (x . y) mod p of two natural-order limbs as centred doubles in B register order (fused multiply + relinearize; direct
 // B-order loads, 16-coefficient geometry only). In-range operands: |x|, |y| <= p/2 after centring, |x.y mod p| <= 0.7p.
 template <class G>
@@ -152,17 +159,11 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
         __builtin_amdgcn_sched_barrier(0);
     }
 #if KX_NEXT_MODE == 1
-    // the next input is requested in ONE burst behind the last key: vector memory returns in order, so a slow (HBM)
-    // request between two key requests delays every key behind it
 #pragma unroll
     for (int r = 0; r < G::E; ++r)
         v[r] = NEXT_B ? (next + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))] : (next + G::idxA(r, 0))[u32(tid)];
 #endif
 }
-
-// Both kernels are ONE loop around ONE inlined instance of each transform they need: at 32 coefficients per thread a
-// transform is ~20 KB of straight-line code, and the two CUs that share a 64 KB instruction cache must hold the whole
-// loop body (a first version with a transform instance per phase -- 65-76 KB per kernel -- ran at half the speed).
 
 // ---- special slot: steps 1-4 for one instance -------------------------------------------------------------------
 // step 4 for one k: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2) (mod q_sp), canonical   (intt2_redu.hpp:25,43)

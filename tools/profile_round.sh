@@ -7,17 +7,20 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/kt $OUT/pmc
-rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py > $OUT/bench_under_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu > $OUT/bench_under_trace.log 2>&1
 python3 $R/tools/rocprof_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_trace.txt 2>&1
 python3 $R/tools/overlap.py $(find $OUT/kt -name "*.db" | head -1) >> $OUT/kernel_trace.txt 2>&1
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   # one lane: every dispatch is one whole chunk of 256 keyswitches, so per-dispatch averages divide by 256
   HEXL_KS_ONE_LANE=1 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc/p$i -- python $R/tools/profile_ks.py 256 7 > /dev/null 2>&1
 done
 python3 $R/tools/pmc_summary.py $OUT/pmc 256 7 > $OUT/pmc.txt 2>&1
 cp $OUT/pmc/traffic.json $OUT/traffic.json 2>/dev/null
+cp $OUT/pmc/alu.json $OUT/alu.json 2>/dev/null
+rm -rf $OUT/pmc $OUT/kt
 python $R/bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 tail -3 $OUT/pmc.txt
