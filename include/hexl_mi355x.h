@@ -87,7 +87,10 @@ int hexl_ks_plan_destroy(hexl_ks_plan* plan);
 /* h_keys[d] -> key words k_switch_keys[d][(k*K + i)*n + j] (fpga.cpp:1186-1190), d < L */
 int hexl_ks_set_keys(hexl_ks_plan* plan, const uint64_t* const* h_keys);
 /* d_t_target[batch][L][n]; d_result[batch][2][L][n] is read-modify-write: the keyswitch
- * output is added into it mod q_i (fpga.cpp:441-475). Steps load -> INTT -> mod-up -> NTT ->
+ * output is added into it mod q_i (fpga.cpp:441-475). Precondition, as for intel::hexl::KeySwitch:
+ * every t_target / result word is below its modulus (the FP64 kernels used for moduli < 2^52 compute
+ * the exact residues of in-range data; the integer kernels used for larger moduli replay the lazy
+ * arithmetic on raw words instead -- out-of-range inputs are outside the contract on both). Steps load -> INTT -> mod-up -> NTT ->
  * key MAC -> INTT(special) -> round -> NTT -> mod-switch -> store of
  * device/keyswitch/ (SURVEY 2.1-K4). */
 int hexl_keyswitch(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_target,
