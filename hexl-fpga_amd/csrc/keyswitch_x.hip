@@ -36,6 +36,9 @@ using namespace hx;
 #ifndef KX_NEXT_MODE
 #define KX_NEXT_MODE 0
 #endif
+#ifndef KX_EARLY_KEYS
+#define KX_EARLY_KEYS 0      // 1: first key pairs requested before the last transform pass -- measured slower (13.9 k vs 9.4 k cycles per multiply-accumulate)
+#endif
 #ifndef KX_TF
 #define KX_TF 0      // twiddle ring of the transforms (ntt_core_f64.hpp); 0 = off
 #endif
@@ -139,13 +142,21 @@ __device__ __forceinline__ void load_product_to_B(double (&v)[G::E], const u64* 
 template <class G>
 __device__ __forceinline__ int in_pos(int r, int tid) { return G::KL <= 2 ? G::idxB(r, tid) : G::idxA(r, tid); }
 
-template <class G, bool NEXT_B = false, int PF = 6>
+constexpr int KX_PF = 6;
+// the first KX_PF key pairs of a multiply-accumulate: requested by the caller before the transform's last pass
+// (KX_EARLY_KEYS) so that their latency is behind them when the products start
+template <class G>
+__device__ __forceinline__ void key_ring_fill(double (&ka)[KX_PF], double (&kb)[KX_PF], const double* __restrict__ k0,
+                                              const double* __restrict__ k1, int tid) {
+#pragma unroll
+    for (int r = 0; r < KX_PF; ++r) { ka[r] = (k0 + r * G::T)[u32(tid)]; kb[r] = (k1 + r * G::T)[u32(tid)]; }
+}
+template <class G, bool NEXT_B = false>
 __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
+                                         double (&ka)[KX_PF], double (&kb)[KX_PF],
                                          const double* __restrict__ k0, const double* __restrict__ k1,
                                          const double* __restrict__ next, int tid, const Mod m) {
-    double ka[PF], kb[PF];
-#pragma unroll
-    for (int r = 0; r < PF; ++r) { ka[r] = (k0 + r * G::T)[u32(tid)]; kb[r] = (k1 + r * G::T)[u32(tid)]; }
+    constexpr int PF = KX_PF;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
         const double a = ka[r % PF], b = kb[r % PF];
@@ -164,6 +175,16 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
         v[r] = NEXT_B ? (next + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))] : (next + G::idxA(r, 0))[u32(tid)];
 #endif
 }
+
+template <class G, bool NEXT_B = false>
+__device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
+                                         const double* __restrict__ k0, const double* __restrict__ k1,
+                                         const double* __restrict__ next, int tid, const Mod m) {
+    double ka[KX_PF], kb[KX_PF];
+    key_ring_fill<G>(ka, kb, k0, k1, tid);
+    mac_keys<G, NEXT_B>(acc0, acc1, v, ka, kb, k0, k1, next, tid, m);
+}
+
 
 // ---- special slot: steps 1-4 for one instance -------------------------------------------------------------------
 // step 4 for one k: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2) (mod q_sp), canonical   (intt2_redu.hpp:25,43)
@@ -242,11 +263,19 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], msp.m);                 // intt1_redu.hpp:36-42
         KX_STAMP(4 * it + 1);
-        W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
-        KX_STAMP(4 * it + 2);
         const double* k0 = a.keys + ((size_t(it) * (L + 1) + L) * 2) * G::N;
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
+#if KX_EARLY_KEYS
+        double ka[KX_PF], kb[KX_PF];
+        W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m, typename W::NoHook(),
+                                          [&] { key_ring_fill<G>(ka, kb, k0, k0 + G::N, tid); });
+        KX_STAMP(4 * it + 2);
+        mac_keys<G>(acc0, acc1, v, ka, kb, k0, k0 + G::N, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
+#else
+        W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
+        KX_STAMP(4 * it + 2);
         mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
+#endif
     }
     {
         int tid = threadIdx.x;
@@ -396,12 +425,20 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);                 // intt1_redu.hpp:36-42
         KX_STAMP(4 * it + 1);
-        W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
-        KX_STAMP(4 * it + 2);
         u32 nit = it + 1;
         if (nit == i) ++nit;
         const double* k0 = a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N;
+#if KX_EARLY_KEYS
+        double ka[KX_PF], kb[KX_PF];
+        W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m, typename W::NoHook(),
+                                          [&] { key_ring_fill<G>(ka, kb, k0, k0 + G::N, tid); });   // |u| <= 2.14p
+        KX_STAMP(4 * it + 2);
+        mac_keys<G>(acc0, acc1, v, ka, kb, k0, k0 + G::N, round_src(nit), tid, m);   // nit <= L: s'_0 follows the last c_d
+#else
+        W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
+        KX_STAMP(4 * it + 2);
         mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
+#endif
         it = nit;
     }
     // rounds L, L+1 (k = 0, 1)

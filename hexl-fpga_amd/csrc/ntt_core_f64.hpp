@@ -124,9 +124,12 @@ struct WgNttF64 {
     // `after_cross` runs right after the first (cross-wave) re-deal: the place to request data the epilogue will
     // need (the barriers and fences of the re-deals pin every load the compiler sees behind them).
     struct NoHook { __device__ __forceinline__ void operator()() const {} };
-    template <int PASS, bool FRESH = false, bool FINAL = true, class Hook = NoHook>
+    // `before_last` runs between the last re-deal and the partial pass (keyswitch_x.hip requests the first keys of the
+    // multiply-accumulate there).
+    template <int PASS, bool FRESH = false, bool FINAL = true, class Hook = NoHook, class Hook2 = NoHook>
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
-                                                    const double* wp, const Mod m, Hook after_cross = Hook()) {
+                                                    const double* wp, const Mod m, Hook after_cross = Hook(),
+                                                    Hook2 before_last = Hook2()) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
@@ -135,8 +138,9 @@ struct WgNttF64 {
             constexpr bool LEAD = !(FRESH && PASS == 0);
             redeal_pass<G, LO, LOGE, true, LEAD, (PASS + 1 == G::P - 1)>(v, lds, tid);
             if constexpr (PASS == 0) after_cross();
-            fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m);
+            fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m, NoHook(), before_last);
         } else {
+            before_last();
             fwd_last<0, FINAL>(v, tid, w, wp, m);
         }
     }
@@ -150,11 +154,12 @@ struct WgNttF64 {
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }
-    template <bool FRESH = false, bool FINAL = true, class Hook = NoHook>
+    template <bool FRESH = false, bool FINAL = true, class Hook = NoHook, class Hook2 = NoHook>
     __device__ static __forceinline__ void forward(double (&v)[E], double* lds, int tid, const double* w,
-                                                   const double* wp, const Mod m, Hook after_cross = Hook()) {
+                                                   const double* wp, const Mod m, Hook after_cross = Hook(),
+                                                   Hook2 before_last = Hook2()) {
         static_assert(G::P > 1, "single-pass geometries are not used");
-        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m, after_cross);
+        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m, after_cross, before_last);
     }
     // every pass except the last (partial) one, ending with the re-deal into B layout; fwd_last<0> finishes.
     // Lets a persistent kernel slot the next polynomial's loads between the two.
