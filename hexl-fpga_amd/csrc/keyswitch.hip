@@ -210,10 +210,39 @@ size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
     return 2 * chunk * scratch_words(p) * p->n * sizeof(u64);      // two lanes
 }
 
+// HEXL_KS_VALIDATE=1: the keyswitch precondition (every t_target / result word below its modulus), checked on the device
+__global__ void k_ks_validate(const u64* __restrict__ t, const u64* __restrict__ res, const KsModulus* __restrict__ mods,
+                              u32 L, u32 n, size_t batch, u32* __restrict__ bad) {
+    const size_t per_t = size_t(L) * n, per_r = 2 * per_t, total = batch * (per_t + per_r);
+    bool out = false;
+    for (size_t g = size_t(blockIdx.x) * blockDim.x + threadIdx.x; g < total; g += size_t(gridDim.x) * blockDim.x) {
+        u64 word; u32 limb;
+        if (g < batch * per_t) { word = t[g]; limb = u32((g % per_t) / n); }
+        else { const size_t h = g - batch * per_t; word = res[h]; limb = u32(((h % per_r) / n) % L); }
+        out |= word >= mods[limb].q;
+    }
+    if (out) atomicOr(bad, 1u);
+}
+
+static int validate_inputs(hexl_ks_plan* p, const u64* d_result, const u64* d_t_target, size_t batch) {
+    u32* d_bad = nullptr;
+    HX_CHECK(hipMalloc((void**)&d_bad, sizeof(u32)));
+    HX_CHECK(hipMemsetAsync(d_bad, 0, sizeof(u32), p->ctx->stream));
+    hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, d_result, p->d_mods, p->L, p->n, batch, d_bad);
+    u32 bad = 0;
+    HX_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
+    HX_CHECK(hipStreamSynchronize(p->ctx->stream));
+    HX_CHECK(hipFree(d_bad));
+    return bad ? HEXL_E_RANGE : 0;
+}
+
 int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
                         hipEvent_t* ev) {
     if (!batch) return 0;
     if (!p->have_keys) return HEXL_E_NOKEYS;
+    static const bool validate = [] { const char* e = getenv("HEXL_KS_VALIDATE"); return e && atoi(e) == 1; }();
+    if (validate)
+        if (int rc = validate_inputs(p, d_result, d_t_target, batch)) return rc;
     // chunks alternate between two lanes; a batch that fits one chunk is still split in two when it is large
     // enough to fill the chip twice, so the lanes always have something to overlap. Timing runs (ev) stay on one lane.
     size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();

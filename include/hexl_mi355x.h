@@ -27,6 +27,7 @@ extern "C" {
 #define HEXL_E_BADARG   (-1)   /* unsupported n / null pointer / size limit */
 #define HEXL_E_NOKEYS   (-2)   /* hexl_keyswitch before hexl_ks_set_keys */
 #define HEXL_E_NODEVICE (-3)   /* no gfx950 device visible */
+#define HEXL_E_RANGE    (-4)   /* HEXL_KS_VALIDATE=1: a t_target / result word is not below its modulus */
 
 typedef struct hexl_ctx hexl_ctx;         /* one per GPU: stream + scratch */
 typedef struct hexl_ks_plan hexl_ks_plan; /* keyswitch parameter set: tables + keys on device */
@@ -90,7 +91,10 @@ int hexl_ks_set_keys(hexl_ks_plan* plan, const uint64_t* const* h_keys);
  * output is added into it mod q_i (fpga.cpp:441-475). Precondition, as for intel::hexl::KeySwitch:
  * every t_target / result word is below its modulus (the FP64 kernels used for moduli < 2^52 compute
  * the exact residues of in-range data; the integer kernels used for larger moduli replay the lazy
- * arithmetic on raw words instead -- out-of-range inputs are outside the contract on both). Steps load -> INTT -> mod-up -> NTT ->
+ * arithmetic on raw words instead -- out-of-range inputs are outside the contract on both).
+ * With HEXL_KS_VALIDATE=1 in the environment every call first checks that precondition on the device
+ * (one extra pass over the inputs and a stream synchronisation) and returns HEXL_E_RANGE without
+ * touching `result` if it does not hold. Steps load -> INTT -> mod-up -> NTT ->
  * key MAC -> INTT(special) -> round -> NTT -> mod-switch -> store of
  * device/keyswitch/ (SURVEY 2.1-K4). */
 int hexl_keyswitch(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_target,

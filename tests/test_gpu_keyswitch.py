@@ -7,6 +7,8 @@ import pytest
 from ks_util import KsCase, primes_below
 
 pytestmark = pytest.mark.gpu
+from pathlib import Path  # noqa: E402
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def run_gpu(hx, ctx, dev, case, ts, rs):
@@ -22,7 +24,8 @@ def run_gpu(hx, ctx, dev, case, ts, rs):
 
 
 @pytest.mark.parametrize("n,L,K", [(1024, 1, 2), (1024, 3, 4), (2048, 2, 3), (4096, 5, 7), (8192, 6, 7),
-                                   (16384, 6, 7), (16384, 7, 8), (16384, 2, 7), (32768, 3, 4)])
+                                   (16384, 6, 7), (16384, 7, 8), (16384, 2, 7), (16384, 15, 16), (32768, 3, 4),
+                                   (32768, 6, 7)])
 def test_vs_oracle(hx, ctx, dev, orc, n, L, K):
     case = KsCase(orc, n, L, K, seed=n + L)
     nb = 3 if n >= 8192 else 5
@@ -32,7 +35,8 @@ def test_vs_oracle(hx, ctx, dev, orc, n, L, K):
         assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"instance {b}"
 
 
-@pytest.mark.parametrize("which", ["f64_lazy_51bit", "f64_strict_just_below_2^52", "int_55bit", "int_forced_51bit",
+@pytest.mark.parametrize("which", ["f64_lazy_51bit", "f64_strict_just_below_2^52", "int_55bit", "int_59bit", "int_just_below_2^60",
+                                   "int_forced_51bit",
                                    "f64_strict_forced_51bit", "mixed_30_to_52bit", "f64_period6_just_below_2^50",
                                    "f64_period12_just_below_2^49", "f64_period3_forced_on_48bit"])
 def test_every_arithmetic_path(hx, ctx, dev, orc, monkeypatch, which):
@@ -44,6 +48,10 @@ def test_every_arithmetic_path(hx, ctx, dev, orc, monkeypatch, which):
         moduli = primes_below(orc, K, 1 << 52, n)
     elif which == "int_55bit":
         moduli = orc.primes(K, 55, n)
+    elif which == "int_59bit":                              # the top of the integer kernels' range: 2^59 < q < 2^60
+        moduli = orc.primes(K, 59, n)
+    elif which == "int_just_below_2^60":
+        moduli = primes_below(orc, K, 1 << 60, n)
     elif which == "mixed_30_to_52bit":                      # like the SEAL bridge run: 52,30,30,40,... bit primes
         moduli = [primes_below(orc, 1, 1 << 52, n)[0], orc.primes(1, 30, n)[0], orc.primes(1, 40, n)[0],
                   orc.primes(2, 51, n)[1]]
@@ -241,3 +249,36 @@ def test_full_baseline_batch_properties(hx, ctx, dev, orc):
     ctx.sync()
     assert torch.equal((r1 - r) % q, delta), "second launch added a different amount"
     plan.close()
+
+
+def test_optional_input_validation(hx, ctx, dev, orc):
+    """HEXL_KS_VALIDATE=1 (read once per process, so a child process): a word that is not below its modulus makes the call
+    fail with HEXL_E_RANGE and leaves `result` untouched; in-range data passes and matches the oracle"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+from ks_util import KsCase
+dev = torch.device("cuda:0"); ctx = hx.Context(0)
+case = KsCase(orc, 4096, 3, 4, seed=9)
+plan = hx.KeySwitchPlan(ctx, 4096, 3, 4, 4, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
+t, r = case.inputs(orc, 0)
+d_t, d_r = hx.as_i64(t).to(dev), hx.as_i64(r).to(dev)
+plan.keyswitch(d_r, d_t, 1); ctx.sync()
+assert np.array_equal(hx.to_u64(d_r), case.expected(orc, t, r))
+bad = t.copy(); bad[4096 + 17] = case.moduli[1]            # limb 1, exactly q: out of range
+d_b, d_r2 = hx.as_i64(bad).to(dev), hx.as_i64(r).to(dev)
+try:
+    plan.keyswitch(d_r2, d_b, 1)
+    print("NOT REJECTED")
+except hx.HexlError as e:
+    ctx.sync()
+    print("REJECTED", "-4" in str(e), bool(np.array_equal(hx.to_u64(d_r2), r)))
+''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HEXL_KS_VALIDATE="1"))
+    print(out.stdout[-1000:], out.stderr[-1500:])
+    assert out.returncode == 0 and "REJECTED True True" in out.stdout
