@@ -249,8 +249,10 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     // (FP64 path: with one barrier per transform and steps 1-2 fused, two lanes measure the same as one stream
     // (160 k vs 162 k keyswitch/s), so it runs its chunks back to back on the caller's stream; HEXL_KS_ONE_LANE=0
     // brings the lanes back)
+    // The slot-major pipeline (keyswitch_x.hip) alternates its chunks between the two lanes again: one chunk's three
+    // kernels fill the ragged end of the other's last generation of workgroups (174 k against 160-170 k keyswitch/s).
     const char* lane_env = getenv("HEXL_KS_ONE_LANE");
-    const bool one_lane = lane_env ? atoi(lane_env) == 1 : p->use_f64;
+    const bool one_lane = lane_env ? atoi(lane_env) == 1 : (p->use_f64 && !hx_ks_x_applies(p, chunk));
     const bool two_lanes = !ev && batch >= 64 && !one_lane && !(p->use_f64 && batch <= chunk);
     if (two_lanes && batch <= chunk) chunk = (batch + 1) / 2;
     const size_t lane_words = chunk * scratch_words(p) * p->n;

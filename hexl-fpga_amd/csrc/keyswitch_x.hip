@@ -33,12 +33,6 @@
 
 using namespace hx;
 
-#ifndef KX_NEXT_MODE
-#define KX_NEXT_MODE 0
-#endif
-#ifndef KX_EARLY_KEYS
-#define KX_EARLY_KEYS 0      // 1: first key pairs requested before the last transform pass -- measured slower (13.9 k vs 9.4 k cycles per multiply-accumulate)
-#endif
 #ifndef KX_TF
 #define KX_TF 0      // twiddle ring of the transforms (ntt_core_f64.hpp); 0 = off
 #endif
@@ -122,8 +116,50 @@ __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* 
 // its register receives word r of the NEXT round's input (`next`, A order; never null), so that input crosses
 // the memory system during this multiply-accumulate instead of stalling the next transform. A scheduling barrier per
 // coefficient keeps the compiler from hoisting the whole stream to the top (and spilling what it displaced).
-// (KX_NEXT_MODE 1 requests the next input in one burst behind the last key instead: the same within noise at four
-// waves per SIMD, 10.4 k against 9.5 k cycles per multiply-accumulate in the timeline tool.)
+// (Requesting the next input in one burst behind the last key instead measured the same within noise at four waves per
+// SIMD: 10.4 k against 9.5 k cycles per multiply-accumulate in the timeline tool.)
+constexpr int KX_PF = 6;
+// The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads: resource descriptor
+// in SGPRs, the thread's byte offset in one VGPR, the row offset in an SGPR -- no 64-bit VALU address arithmetic (global
+// loads at row strides beyond the 13-bit immediate cost a v_add_co / v_addc pair and a hazard nop each: ~6 % of the
+// kernel's VALU instructions).
+struct RowStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ RowStream(const double* base, u32 bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ double at(u32 thread_byte_offset, u32 row_byte_offset) const {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)thread_byte_offset, (int)row_byte_offset, 0);
+        double d;
+        __builtin_memcpy(&d, &x, 8);
+        return d;
+    }
+};
+
+// acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
+// input, A order (never null)
+template <class G>
+__device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
+                                         const double* __restrict__ k0, const double* __restrict__ next, int tid,
+                                         const Mod m) {
+    constexpr int PF = KX_PF;
+    const RowStream keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
+    const u32 toff = u32(tid) * 8;
+    double ka[PF], kb[PF];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) { ka[r] = keys.at(toff, r * G::T * 8); kb[r] = keys.at(toff, (G::N + r * G::T) * 8); }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const double a = ka[r % PF], b = kb[r % PF];
+        if (r + PF < G::E) { ka[r % PF] = keys.at(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.at(toff, (G::N + (r + PF) * G::T) * 8); }
+        const double x = v[r];
+        v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
+        acc0[r] = hxf::reduce(acc0[r] + hxf::mul_mod(x, a, m), m);
+        acc1[r] = hxf::reduce(acc1[r] + hxf::mul_mod(x, b, m), m);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // (x . y) mod p of two natural-order limbs as centred doubles in B register order (fused multiply + relinearize; direct
 // B-order loads, 16-coefficient geometry only). In-range operands: |x|, |y| <= p/2 after centring, |x.y mod p| <= 0.7p.
 template <class G>
@@ -141,50 +177,6 @@ __device__ __forceinline__ void load_product_to_B(double (&v)[G::E], const u64* 
 // for small lane runs, A order (then re-dealt through LDS) otherwise -- see load_natural_to_B
 template <class G>
 __device__ __forceinline__ int in_pos(int r, int tid) { return G::KL <= 2 ? G::idxB(r, tid) : G::idxA(r, tid); }
-
-constexpr int KX_PF = 6;
-// the first KX_PF key pairs of a multiply-accumulate: requested by the caller before the transform's last pass
-// (KX_EARLY_KEYS) so that their latency is behind them when the products start
-template <class G>
-__device__ __forceinline__ void key_ring_fill(double (&ka)[KX_PF], double (&kb)[KX_PF], const double* __restrict__ k0,
-                                              const double* __restrict__ k1, int tid) {
-#pragma unroll
-    for (int r = 0; r < KX_PF; ++r) { ka[r] = (k0 + r * G::T)[u32(tid)]; kb[r] = (k1 + r * G::T)[u32(tid)]; }
-}
-template <class G, bool NEXT_B = false>
-__device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
-                                         double (&ka)[KX_PF], double (&kb)[KX_PF],
-                                         const double* __restrict__ k0, const double* __restrict__ k1,
-                                         const double* __restrict__ next, int tid, const Mod m) {
-    constexpr int PF = KX_PF;
-#pragma unroll
-    for (int r = 0; r < G::E; ++r) {
-        const double a = ka[r % PF], b = kb[r % PF];
-        if (r + PF < G::E) { ka[r % PF] = (k0 + (r + PF) * G::T)[u32(tid)]; kb[r % PF] = (k1 + (r + PF) * G::T)[u32(tid)]; }
-        const double x = v[r];
-#if KX_NEXT_MODE == 0
-        v[r] = NEXT_B ? (next + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))] : (next + G::idxA(r, 0))[u32(tid)];
-#endif
-        acc0[r] = hxf::reduce(acc0[r] + hxf::mul_mod(x, a, m), m);
-        acc1[r] = hxf::reduce(acc1[r] + hxf::mul_mod(x, b, m), m);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#if KX_NEXT_MODE == 1
-#pragma unroll
-    for (int r = 0; r < G::E; ++r)
-        v[r] = NEXT_B ? (next + in_pos<G>(r, 0))[u32(in_pos<G>(0, tid))] : (next + G::idxA(r, 0))[u32(tid)];
-#endif
-}
-
-template <class G, bool NEXT_B = false>
-__device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
-                                         const double* __restrict__ k0, const double* __restrict__ k1,
-                                         const double* __restrict__ next, int tid, const Mod m) {
-    double ka[KX_PF], kb[KX_PF];
-    key_ring_fill<G>(ka, kb, k0, k1, tid);
-    mac_keys<G, NEXT_B>(acc0, acc1, v, ka, kb, k0, k1, next, tid, m);
-}
-
 
 // ---- special slot: steps 1-4 for one instance -------------------------------------------------------------------
 // step 4 for one k: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2) (mod q_sp), canonical   (intt2_redu.hpp:25,43)
@@ -265,17 +257,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
         KX_STAMP(4 * it + 1);
         const double* k0 = a.keys + ((size_t(it) * (L + 1) + L) * 2) * G::N;
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
-#if KX_EARLY_KEYS
-        double ka[KX_PF], kb[KX_PF];
-        W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m, typename W::NoHook(),
-                                          [&] { key_ring_fill<G>(ka, kb, k0, k0 + G::N, tid); });
-        KX_STAMP(4 * it + 2);
-        mac_keys<G>(acc0, acc1, v, ka, kb, k0, k0 + G::N, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
-#else
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
         KX_STAMP(4 * it + 2);
-        mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
-#endif
+        mac_keys<G>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
     }
     {
         int tid = threadIdx.x;
@@ -411,7 +395,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
         }
         KX_STAMP(61);
         const double* k0 = a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N;
-        mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, round_src(first), tid, m);
+        mac_keys<G>(acc0, acc1, v, k0, round_src(first), tid, m);
     }
     // rounds d != i: acc += NTT(c_d mod q_i) . key[d][i]
 #pragma unroll 1
@@ -428,17 +412,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
         u32 nit = it + 1;
         if (nit == i) ++nit;
         const double* k0 = a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N;
-#if KX_EARLY_KEYS
-        double ka[KX_PF], kb[KX_PF];
-        W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m, typename W::NoHook(),
-                                          [&] { key_ring_fill<G>(ka, kb, k0, k0 + G::N, tid); });   // |u| <= 2.14p
-        KX_STAMP(4 * it + 2);
-        mac_keys<G>(acc0, acc1, v, ka, kb, k0, k0 + G::N, round_src(nit), tid, m);   // nit <= L: s'_0 follows the last c_d
-#else
         W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
         KX_STAMP(4 * it + 2);
-        mac_keys<G>(acc0, acc1, v, k0, k0 + G::N, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
-#endif
+        mac_keys<G>(acc0, acc1, v, k0, round_src(nit), tid, m);                      // nit <= L: s'_0 follows the last c_d
         it = nit;
     }
     // rounds L, L+1 (k = 0, 1)
