@@ -199,6 +199,20 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
     using W = WgNttF64<LOGN, LOGE, LAZY, 0>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.L);
+    if (wk.pos >= wk.end) return;
+    // the next item's words are requested into spare registers behind the last per-lane twiddle request of the current
+    // transform (WgNttF64::inverse's `before_uniform` hook; see k_ntt_inv_p): the item loop never waits for its input
+    auto src_of = [&](u32 item) -> const u64* {
+        if constexpr (FUSED) return nullptr;
+        else return a.t_target + size_t(item) * G::N;
+    };
+    u64 raw[G::E];
+    if constexpr (!FUSED && G::KL <= 2) {
+        const u32 tB = u32(G::idxB(0, int(threadIdx.x)));
+        const u64* p0 = src_of(wk.pos);
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
+    }
 #pragma unroll 1
     for (u32 item = wk.pos; item < wk.end; item += wk.step) {     // item = b*L + d
         int tid = threadIdx.x;
@@ -212,10 +226,21 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
         if constexpr (FUSED) {                                    // t_target[d] = a_1[d] . b_1[d]
             const size_t at = ((size_t(item / a.L) * 2 + 1) * a.L + d) * G::N;
             load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, md.m);
+            W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+        } else if constexpr (G::KL <= 2) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(raw[r]), md.m);
+            const u32 nitem = item + wk.step < wk.end ? item + wk.step : item;       // (last round: a harmless re-read)
+            const u64* pn = src_of(nitem);
+            const u32 tB = u32(G::idxB(0, tid));
+            W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, [&] {
+#pragma unroll
+                for (int r = 0; r < G::E; ++r) raw[r] = (pn + G::idxB(r, 0))[tB];
+            });
         } else {
             load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m);
+            W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         }
-        W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         double* cd = a.c + size_t(item) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (cd + G::idxA(r, 0))[u32(tid)] = hxf::lift(v[r], md.m);
