@@ -125,8 +125,15 @@ constexpr int KX_PF = 6;
 // kernel's VALU instructions).
 struct RowStream {
     __amdgpu_buffer_rsrc_t rsrc;
+    // (the base is wave-uniform by construction; saying so keeps the compiler from wrapping every load in a
+    // "waterfall" loop over the distinct descriptors of a wave)
+    __device__ __forceinline__ static double* uniform(const double* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const u32 lo = __builtin_amdgcn_readfirstlane(u32(v)), hi = __builtin_amdgcn_readfirstlane(u32(v >> 32));
+        return (double*)(((unsigned long long)hi << 32) | lo);
+    }
     __device__ __forceinline__ RowStream(const double* base, u32 bytes)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, (int)bytes, 0x00020000)) {}
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(uniform(base), 0, (int)bytes, 0x00020000)) {}
     __device__ __forceinline__ double at(u32 thread_byte_offset, u32 row_byte_offset) const {
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
         const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)thread_byte_offset, (int)row_byte_offset, 0);
