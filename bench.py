@@ -317,7 +317,7 @@ def main():
             # the same shape with 48-bit primes (SEAL's default parameter sizes for N=16384): longer lazy-reduction period
             extra["keyswitch_16384_6_7_7_2_48bit_primes"] = other_shape(6, 7, orc_mod.primes(7, 48, N))
         out["extra"] = extra
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:                            # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(orc_mod, case)
         print(json.dumps(out))
     plan.close()
