@@ -282,3 +282,35 @@ except hx.HexlError as e:
                          env=dict(os.environ, HEXL_KS_VALIDATE="1"))
     print(out.stdout[-1000:], out.stderr[-1500:])
     assert out.returncode == 0 and "REJECTED True True" in out.stdout
+
+
+@pytest.mark.parametrize("env", [{"HEXL_KS_PIPE": "1"}, {"HEXL_KSX_LOGE": "5", "HEXL_KS_PIPE": "3"}, {"HEXL_KSX_PERSIST": "0"},
+                                 {"HEXL_KS_ONE_LANE": "1"}],
+                         ids=["bd_major_pipeline", "slot_major_32x512", "slot_major_one_item_per_workgroup", "one_lane"])
+def test_alternative_pipelines_agree_with_the_oracle(env):
+    """the kernels the default no longer selects for a large N = 16384 batch -- the (b, d)-major pipeline of round 1
+    (k_ksf_up / k_ksf_mac / ...), the 32 x 512 geometry of the slot-major one, its non-persistent grids, a single lane --
+    must still give the oracle's bits (the knobs are read once per process, hence a child process each)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+from ks_util import KsCase
+dev = torch.device("cuda:0"); ctx = hx.Context(0)
+n, L, K, nb = 16384, 6, 7, 300
+case = KsCase(orc, n, L, K, seed=77)
+plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
+ins = [case.inputs(orc, b) for b in range(3)]
+d_t = hx.as_i64(np.concatenate([ins[b %% 3][0] for b in range(nb)])).to(dev)
+d_r = hx.as_i64(np.concatenate([ins[b %% 3][1] for b in range(nb)])).to(dev)
+plan.keyswitch(d_r, d_t, nb); ctx.sync()
+out = hx.to_u64(d_r).reshape(nb, -1)
+want = [case.expected(orc, t, r) for t, r in ins]
+print("OK" if all(np.array_equal(out[b], want[b %% 3]) for b in range(nb)) else "MISMATCH")
+''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    print(out.stdout[-500:], out.stderr[-1500:])
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK")
