@@ -62,6 +62,58 @@ __global__ __launch_bounds__(1024) void k_timeline(double* x, const double* w, c
     STAMP(10, "s_waitcnt vmcnt(0)");
 }
 
+// persistent variant (the shape of k_ntt_fwd_p, ntt.hip): one workgroup per CU walks the batch, next input requested
+// into spare registers right after the conversion of the current one; u64 in / out like the product kernel
+__global__ __launch_bounds__(1024) void k_timeline_p(unsigned long long* x, const double* w, const double* wp, Mod m,
+                                                     unsigned long long* stamps, unsigned batch) {
+    using G = Geom<14, 4>;
+    using W = WgNttF64<14, 4, 3>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    unsigned long long raw[G::E];
+    {
+        const int tid = threadIdx.x;
+        const unsigned long long* p0 = x + size_t(blockIdx.x) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
+    }
+    unsigned it = 0;
+#pragma unroll 1
+    for (unsigned p = blockIdx.x; p < batch; p += gridDim.x, ++it) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        unsigned long long* st = stamps + ((size_t(blockIdx.x) * 8 + it) * 16 + (tid >> 6)) * NST;
+        unsigned long long* px = x + size_t(p) * G::N;
+        double v[G::E];
+        if ((tid & 63) == 0) st[0] = now();
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
+        STAMP(1, "");
+        const unsigned pn = p + gridDim.x < batch ? p + gridDim.x : p;
+        const unsigned long long* pnx = x + size_t(pn) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
+        fwd_stages_f64<16, 0, 4, 1, 14, 3, true>(v, 0u, w, wp, m);
+        STAMP(2, "");
+        redeal_x<G, false, true>(v, ldsd, tid, [](int r, int t) { return G::idxF<10>(r, t); }, [](int r, int t) { return G::idxF<6>(r, t); });
+        STAMP(3, "s_waitcnt lgkmcnt(0)");
+        fwd_stages_f64<16, 0, 4, 5, 14, 3, true>(v, u32(__builtin_amdgcn_readfirstlane(u32(tid) >> 6)), w, wp, m);
+        STAMP(4, "");
+        redeal_x<G, true, false>(v, ldsd, tid, [](int r, int t) { return G::idxF<6>(r, t); }, [](int r, int t) { return G::idxF<2>(r, t); });
+        STAMP(5, "s_waitcnt lgkmcnt(0)");
+        fwd_stages_f64<16, 0, 4, 9, 14, 3>(v, u32(tid) >> 2, w, wp, m);
+        STAMP(6, "");
+        redeal_x<G, true, false>(v, ldsd, tid, [](int r, int t) { return G::idxF<2>(r, t); }, [](int r, int t) { return G::idxB(r, t); });
+        STAMP(7, "s_waitcnt lgkmcnt(0)");
+        W::template fwd_last<0>(v, tid, w, wp, m);
+        STAMP(8, "");
+        __syncthreads();                                          // stands in for the vote of k_ntt_fwd_p
+        STAMP(9, "");
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(v[r], m));
+        STAMP(10, "");
+    }
+}
+
 int main(int argc, char** argv) {
     using G = Geom<14, 4>;
     const int N = 16384, batch = argc > 1 ? atoi(argv[1]) : 2048;
@@ -119,6 +171,42 @@ int main(int argc, char** argv) {
         for (size_t i = 1; i < vv.size(); ++i) { gap += double((long long)(vv[i].first - vv[i - 1].second)); ++ngap; }
     }
     printf("  %zu distinct CUs seen; mean gap between a workgroup's last stamp and the next one's first on the same CU: %.0f cycles\n", per_cu.size(), ngap ? gap / ngap : 0.0);
+    }
+    {   // persistent kernel: 256 workgroups x (batch / 256) polynomials each (<= 8)
+        const unsigned pb = batch > 2048 ? 2048 : batch;
+        std::vector<unsigned long long> hx(size_t(pb) * N);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = (i * 2654435761ull) % 2251799814045697ull;
+        unsigned long long* dx; hipMalloc(&dx, hx.size() * 8);
+        unsigned long long* stp; hipMalloc(&stp, size_t(256) * 8 * 16 * NST * 8);
+        hipFuncSetAttribute((const void*)k_timeline_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipMemcpy(dx, hx.data(), hx.size() * 8, hipMemcpyHostToDevice);
+            hipMemset(stp, 0, size_t(256) * 8 * 16 * NST * 8);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_timeline_p, dim3(256), dim3(G::T), G::LDS_BYTES, 0, dx, w, wp, m, stp, pb);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        const int iters = pb / 256;
+        std::vector<unsigned long long> s(size_t(256) * 8 * 16 * NST);
+        hipMemcpy(s.data(), stp, s.size() * 8, hipMemcpyDeviceToHost);
+        printf("---- persistent, next input prefetched: %.3f ms for %u transforms = %.2f us per transform per CU (instrumented)\n", ms, pb, ms * 1e3 / iters);
+        const char* names[] = {"convert (waits for the prefetched input)", "request next + pass 0", "cross-wave re-deal (barrier)", "pass 1", "private re-deal", "pass 2", "private re-deal", "pass 3 (2 stages)", "end barrier (vote)", "lift + issue stores"};
+        for (int it = 0; it < iters; ++it) {
+            double acc[NST] = {0}; double tot = 0; double nextgap = 0; int ng = 0;
+            for (int b = 0; b < 256; ++b)
+                for (int wv = 0; wv < 16; ++wv) {
+                    const unsigned long long* q = &s[((size_t(b) * 8 + it) * 16 + wv) * NST];
+                    for (int i = 0; i < 10; ++i) acc[i] += double(q[i + 1] - q[i]);
+                    if (it + 1 < iters) { const unsigned long long* qn = &s[((size_t(b) * 8 + it + 1) * 16 + wv) * NST]; nextgap += double(qn[0] - q[10]); ++ng; }
+                }
+            printf("  iteration %d:\n", it);
+            for (int i = 0; i < 10; ++i) { acc[i] /= 256.0 * 16; tot += acc[i]; }
+            for (int i = 0; i < 10; ++i) printf("    %-44s %8.0f cycles  %5.1f %%\n", names[i], acc[i], 100 * acc[i] / tot);
+            printf("    %-44s %8.0f cycles; to the next iteration's first stamp %.0f\n", "sum", tot, ng ? nextgap / ng : 0.0);
+        }
     }
     return 0;
 }
