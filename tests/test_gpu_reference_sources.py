@@ -31,6 +31,18 @@ def test_reference_benchmark_binary_runs(exe):
     assert out.returncode == 0 and "ms" in out.stdout
 
 
+def test_reference_example_program():
+    """examples/examples.cpp + example_dyadic_multiply.cpp unmodified (the reference's `make examples` target,
+    examples/CMakeLists.txt:18-24): 40 multiplications at N = 8192, 6 moduli, checked against the example's own CPU result"""
+    path = BUILD / "example_dyadic_multiply"
+    if not path.exists():
+        pytest.skip("reference example sources were not built on this box")
+    out = subprocess.run([str(path)], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-1500:], out.stderr[-500:])
+    assert out.returncode == 0 and "Correct multiplication: both vectors are equal" in out.stdout
+    assert "Error" not in out.stdout
+
+
 def _vectors(tmp, n, shapes, count=2):
     """the directory the reference sources read their JSON vectors from. If the caller's environment already points
     KEYSWITCH_DATA_DIR at the OFFICIAL vectors (testdata.zip, README.md:166-176: files <n>_<L>_<K>_<rns>_2_*.json), those are
