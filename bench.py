@@ -316,6 +316,8 @@ def main():
             extra["keyswitch_16384_6_7_7_2"] = other_shape(6, 7)
             # the same shape with 48-bit primes (SEAL's default parameter sizes for N=16384): longer lazy-reduction period
             extra["keyswitch_16384_6_7_7_2_48bit_primes"] = other_shape(6, 7, orc_mod.primes(7, 48, N))
+            # the headline shape on the 64-bit INTEGER kernels (59-bit primes: beyond the reference's < 2^52 envelope)
+            extra["keyswitch_16384_L%d_59bit_primes_integer_kernels" % L] = other_shape(L, L + 1, orc_mod.primes(L + 1, 59, N))
         out["extra"] = extra
         if not a.no_cpu and world == 1:                            # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(orc_mod, case)

@@ -204,6 +204,11 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
     p->use_f64 = f64_ok;
     p->f64_lazy = 0;
     p->f64_loge = ks_loge(logn, true);
+    p->int_loge = ks_loge(logn, false);
+    if (logn == 14) {                                             // HEXL_KSI_LOGE=4: 16 coefficients x 1024 threads
+        const char* e = getenv("HEXL_KSI_LOGE");
+        if (e && (atoi(e) == 4 || atoi(e) == 5)) p->int_loge = (u32)atoi(e);
+    }
     if (f64_ok && !(getenv("HEXL_KS_NOLAZY") && atoi(getenv("HEXL_KS_NOLAZY")) == 1)) {
         double qmax = 0;
         for (u64 i = 0; i < K; ++i) qmax = (double)h_moduli[i] > qmax ? (double)h_moduli[i] : qmax;
@@ -277,7 +282,7 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     if (!p || !h_keys) return HEXL_E_BADARG;
     HX_CHECK(hipSetDevice(p->ctx->device));
     const u64 n = p->n, L = p->L, K = p->K;
-    const std::vector<u32> perm = ks_perm(p->logn, ks_loge(p->logn, false));
+    const std::vector<u32> perm = ks_perm(p->logn, p->int_loge);
     std::vector<u64> dev(size_t(L) * (L + 1) * 2 * n);
     std::vector<double> devf, devx;
     std::vector<u32> permf, permx;

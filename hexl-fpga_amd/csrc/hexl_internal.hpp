@@ -91,6 +91,7 @@ struct hexl_ks_plan {
     KsModulus* d_mods = nullptr;      // [K]
     u64* d_tables = nullptr;          // [K][4][n]: roots, precon, inv_roots(HEXL idx), inv_precon
     u64* d_keys = nullptr;            // [L][L+1][2][n] in forward-output ("B") order
+    u32 int_loge = 5;                 // elements-per-thread exponent of the integer kernels (fixes that B order)
     bool have_keys = false;
     // FP64 path (all moduli < 2^52): same tables / keys as centred doubles
     bool use_f64 = false;

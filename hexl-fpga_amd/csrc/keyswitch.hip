@@ -163,6 +163,208 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_moddown(KsArgs a) {
     }
 }
 
+// ---- second generation (HEXL_KS_PIPE != 1): prod[k][i] never leaves the registers -------------------------------------
+// The layout of keyswitch_x.hip with the integer butterflies: one workgroup per (instance, limb) carries the two
+// accumulators through steps 2-3 AND 5-7 (`prod` and the k_ks_moddown launch are gone), the special slot has its own
+// kernel, the d == i round uses t_target[i] itself (NTT(INTT(t_i)) = t_i for in-range data), and every
+// multiply-accumulate requests the next round's input into the registers its products free.
+//
+//   k_ks_intt     (b, d)    c_d = INTT_{q_d}(t_target[d])                                           (step 1, as above)
+//   k_ksi_special (b)       acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k];  s'_k = INTT(acc_k) + floor(q_sp/2)
+//   k_ksi_main    (b, i<L)  acc_k = sum_d NTT_{q_i}(c_d mod q_i) . key[d][i][k]; then for k = 0, 1:
+//                           w = NTT_{q_i}((s'_k + fix_i) mod q_i);  result[k][i] += (acc_k - w) . msf_i
+
+// acc_k += v . key_k (dyadmult.hpp:128-140); v[r] is replaced by word r of `next` (A order, never null)
+template <class G>
+__device__ __forceinline__ void mac_keys_i(u64 (&acc0)[G::E], u64 (&acc1)[G::E], u64 (&v)[G::E], const u64* __restrict__ k0,
+                                           const u64* __restrict__ next, int tid, const KsModulus& md) {
+#ifndef KSI_PF32
+#define KSI_PF32 8
+#define KSI_PF16 4
+#endif
+    constexpr int PF = G::E >= 32 ? KSI_PF32 : KSI_PF16;
+    const RowStream<u64> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
+    const u32 toff = u32(tid) * 8, len = u32(md.len);
+    const u64 q = md.q;
+    u64 ka[PF], kb[PF];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) { ka[r] = keys.at(toff, r * G::T * 8); kb[r] = keys.at(toff, (G::N + r * G::T) * 8); }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const u64 ca = ka[r % PF], cb = kb[r % PF];
+        if (r + PF < G::E) { ka[r % PF] = keys.at(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.at(toff, (G::N + (r + PF) * G::T) * 8); }
+        const u64 x = v[r];
+        v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
+        acc0[r] = csub(acc0[r] + mulmod128(x, ca, q, len, md.barr_lo), q);
+        acc1[r] = csub(acc1[r] + mulmod128(x, cb, q, len, md.barr_lo), q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_special(KsArgs a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNtt<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u32 L = a.L, b = blockIdx.x, isp = a.K - 1;
+    const KsModulus md = a.mods[isp];
+    const u64 q = md.q;
+    u64 acc0[G::E], acc1[G::E], v[G::E];                          // v between rounds: the next round's input, A order
+    {
+        const int tid = threadIdx.x;
+        const u64* c0 = a.c + size_t(b) * L * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { acc0[r] = 0; acc1[r] = 0; v[r] = (c0 + G::idxA(r, 0))[u32(tid)]; }
+    }
+#pragma unroll 1
+    for (u32 d = 0; d < L; ++d) {
+        int tid = threadIdx.x;                                    // laundered per round: nothing is hoisted out of the loop
+        asm volatile("" : "+v"(tid));
+        const u64* ts = a.tables + size_t(isp) * 4 * G::N + opaque_zero();
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = barrett64(v[r], q, md.qbarr);             // intt1_redu.hpp:36-42
+        W::forward_lazy(v, lds, tid, ts, ts + G::N, q);
+        W::final_reduce(v, q);
+        const u32 nd = d + 1 < L ? d + 1 : d;                     // (the last limb is requested twice: harmless)
+        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(d) * (L + 1) + L) * 2) * G::N, a.c + (size_t(b) * L + nd) * G::N, tid, md);
+    }
+    // s'_k = INTT(acc_k) + floor(q_sp/2) (mod q_sp)   (intt2_redu.hpp:25,43)
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u64* it = a.tables + size_t(isp) * 4 * G::N + opaque_zero() + 2 * G::N;
+        W::inverse(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        u64* s0 = a.s + (size_t(b) * 2 + 0) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) (s0 + G::idxA(r, 0))[u32(tid)] = csub(acc0[r] + md.half, q);
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u64* it = a.tables + size_t(isp) * 4 * G::N + opaque_zero() + 2 * G::N;
+        W::inverse(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        u64* s1 = a.s + (size_t(b) * 2 + 1) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) (s1 + G::idxA(r, 0))[u32(tid)] = csub(acc1[r] + md.half, q);
+    }
+}
+
+// steps 5-7 for one k: v holds the raw s'_k words (A order); result[k][i] += (acc - NTT((s'_k + fix_i) mod q_i)) . msf_i
+template <class G, class W>
+__device__ __forceinline__ void ksi_down_round(u64 (&v)[G::E], const u64 (&acc)[G::E], u64* __restrict__ res, u64* lds, int tid,
+                                               const u64* tb, const KsModulus& md) {
+    const u64 q = md.q;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = barrett64(v[r] + md.fix, q, md.qbarr);       // intt2_redu.hpp:49-51
+    W::forward_lazy(v, lds, tid, tb, tb + G::N, q);
+    W::final_reduce(v, q);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const u64 in = csub(acc[r] + q - v[r], q);                                      // ms.hpp:70-78 (canonical)
+        v[r] = csub(lazy_mul(in, md.msf, md.msf_p, q), q);                              // ms.hpp:80-82
+    }
+    // read-modify-write at the thread's own (B) positions, half of the registers at a time (fpga.cpp:453-457)
+    const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+    for (int r0 = 0; r0 < G::E; r0 += G::E / 2) {
+        u64 old[G::E / 2];
+#pragma unroll
+        for (int r = 0; r < G::E / 2; ++r) old[r] = (res + G::idxB(r0 + r, 0))[tB];
+#pragma unroll
+        for (int r = 0; r < G::E / 2; ++r) {
+            const u64 rr = old[r] + v[r0 + r];
+            (res + G::idxB(r0 + r, 0))[tB] = rr >= q ? rr - q : rr;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_main(KsArgs a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNtt<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u32 L = a.L;
+    // instance-major, XCD-contiguous: the L workgroups that read the same c_d and s' run side by side on one XCD
+    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item(blockIdx.x, gridDim.x));
+    const u32 b = item / L, i = item - b * L;
+    const KsModulus md = a.mods[i];
+    const u64 q = md.q;
+    // round `it` reads c_it (it < L, skipping it == i) or s'_{it-L}
+    auto round_src = [&](u32 it) { return it < L ? a.c + (size_t(b) * L + it) * G::N : a.s + (size_t(b) * 2 + (it - L)) * G::N; };
+    const u32 first = i == 0 ? 1u : 0u;
+    u64 acc0[G::E], acc1[G::E], v[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) { acc0[r] = 0; acc1[r] = 0; }
+    {
+        // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i mod q_i (the reference recomputes it)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u64* src = a.t_target + (size_t(b) * L + i) * G::N;
+        const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = barrett64((src + G::idxB(r, 0))[tB], q, md.qbarr);
+        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N, round_src(first), tid, md);
+    }
+#pragma unroll 1
+    for (u32 it = first; it < L;) {                                // rounds d != i
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u64* tb = a.tables + size_t(i) * 4 * G::N + opaque_zero();
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = barrett64(v[r], q, md.qbarr);             // intt1_redu.hpp:36-42
+        u32 nit = it + 1;
+        if (nit == i) ++nit;
+        W::forward_lazy(v, lds, tid, tb, tb + G::N, q);
+        W::final_reduce(v, q);
+        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N, round_src(nit), tid, md);   // nit <= L
+        it = nit;
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u64* tb = a.tables + size_t(i) * 4 * G::N + opaque_zero();
+        ksi_down_round<G, W>(v, acc0, a.result + ((size_t(b) * 2 + 0) * L + i) * G::N, lds, tid, tb, md);
+        const u64* nxt = a.s + (size_t(b) * 2 + 1) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u64* tb = a.tables + size_t(i) * 4 * G::N + opaque_zero();
+        ksi_down_round<G, W>(v, acc1, a.result + ((size_t(b) * 2 + 1) * L + i) * G::N, lds, tid, tb, md);
+    }
+}
+
+template <int LOGN, int LOGE>
+static int run_chunk_i(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_t* ev) {
+    using G = Geom<LOGN, LOGE>;
+    static PerDeviceOnce once;
+    if (int rc = once.run(p->ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ks_intt<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_USED));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ksi_special<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_USED));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ksi_main<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_USED));
+            return 0;
+        }))
+        return rc;
+    hipStream_t st = p->cur;
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1)
+        hipLaunchKernelGGL((k_ks_intt<LOGN, LOGE>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (stage_mask & 2)
+        hipLaunchKernelGGL((k_ksi_special<LOGN, LOGE>), dim3(a.nb), dim3(G::T), G::LDS_USED, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
+    if (stage_mask & 4)
+        hipLaunchKernelGGL((k_ksi_main<LOGN, LOGE>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
+    if (ev) HX_CHECK(hipEventRecord(ev[3], st));
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int LOGN, int LOGE>
 static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_t* ev) {
@@ -304,12 +506,15 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         a.t_target = d_t_target + b0 * L * n;
         a.result = d_result + b0 * 2 * L * n;
         a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
-        switch (p->logn) {
-            case 10: rc = run_chunk<10, 4>(p, a, stage_mask, ev); break;
-            case 11: rc = run_chunk<11, 5>(p, a, stage_mask, ev); break;
-            case 12: rc = run_chunk<12, 5>(p, a, stage_mask, ev); break;
-            case 13: rc = run_chunk<13, 5>(p, a, stage_mask, ev); break;
-            case 14: rc = run_chunk<14, 5>(p, a, stage_mask, ev); break;
+        // HEXL_KS_PIPE=1: the first-generation kernels (k_ks_modup / k_ks_moddown, `prod` through memory)
+        static const bool gen1 = [] { const char* e = getenv("HEXL_KS_PIPE"); return e && atoi(e) == 1; }();
+        switch (p->logn * 8 + p->int_loge) {
+            case 10 * 8 + 4: rc = gen1 ? run_chunk<10, 4>(p, a, stage_mask, ev) : run_chunk_i<10, 4>(p, a, stage_mask, ev); break;
+            case 11 * 8 + 5: rc = gen1 ? run_chunk<11, 5>(p, a, stage_mask, ev) : run_chunk_i<11, 5>(p, a, stage_mask, ev); break;
+            case 12 * 8 + 5: rc = gen1 ? run_chunk<12, 5>(p, a, stage_mask, ev) : run_chunk_i<12, 5>(p, a, stage_mask, ev); break;
+            case 13 * 8 + 5: rc = gen1 ? run_chunk<13, 5>(p, a, stage_mask, ev) : run_chunk_i<13, 5>(p, a, stage_mask, ev); break;
+            case 14 * 8 + 5: rc = gen1 ? run_chunk<14, 5>(p, a, stage_mask, ev) : run_chunk_i<14, 5>(p, a, stage_mask, ev); break;
+            case 14 * 8 + 4: rc = gen1 ? run_chunk<14, 4>(p, a, stage_mask, ev) : run_chunk_i<14, 4>(p, a, stage_mask, ev); break;
             default: rc = HEXL_E_BADARG;
         }
         if (rc) return rc;

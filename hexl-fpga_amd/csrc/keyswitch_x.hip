@@ -119,30 +119,7 @@ __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* 
 // (Requesting the next input in one burst behind the last key instead measured the same within noise at four waves per
 // SIMD: 10.4 k against 9.5 k cycles per multiply-accumulate in the timeline tool.)
 constexpr int KX_PF = 6;
-// The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads: resource descriptor
-// in SGPRs, the thread's byte offset in one VGPR, the row offset in an SGPR -- no 64-bit VALU address arithmetic (global
-// loads at row strides beyond the 13-bit immediate cost a v_add_co / v_addc pair and a hazard nop each: ~6 % of the
-// kernel's VALU instructions).
-struct RowStream {
-    __amdgpu_buffer_rsrc_t rsrc;
-    // (the base is wave-uniform by construction; saying so keeps the compiler from wrapping every load in a
-    // "waterfall" loop over the distinct descriptors of a wave)
-    __device__ __forceinline__ static double* uniform(const double* p) {
-        const unsigned long long v = (unsigned long long)p;
-        const u32 lo = __builtin_amdgcn_readfirstlane(u32(v)), hi = __builtin_amdgcn_readfirstlane(u32(v >> 32));
-        return (double*)(((unsigned long long)hi << 32) | lo);
-    }
-    __device__ __forceinline__ RowStream(const double* base, u32 bytes)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(uniform(base), 0, (int)bytes, 0x00020000)) {}
-    __device__ __forceinline__ double at(u32 thread_byte_offset, u32 row_byte_offset) const {
-        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)thread_byte_offset, (int)row_byte_offset, 0);
-        double d;
-        __builtin_memcpy(&d, &x, 8);
-        return d;
-    }
-};
-
+// The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads (RowStream, ntt_core.hpp).
 // acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
 // input, A order (never null)
 template <class G>
@@ -150,7 +127,7 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
                                          const double* __restrict__ k0, const double* __restrict__ next, int tid,
                                          const Mod m) {
     constexpr int PF = KX_PF;
-    const RowStream keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
+    const RowStream<double> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8;
     double ka[PF], kb[PF];
 #pragma unroll

@@ -72,6 +72,32 @@ __device__ __forceinline__ u32 opaque_zero() {
     return z;
 }
 
+// Rows of 64-bit words (key rows, the next round's input) read with BUFFER loads: resource descriptor in SGPRs, the
+// thread's byte offset in one VGPR, the row offset in an SGPR -- no 64-bit VALU address arithmetic (global loads at row
+// strides beyond the 13-bit immediate cost a v_add_co / v_addc pair and a hazard nop each: ~6 % of the slot-major
+// keyswitch kernel's VALU instructions).
+template <class V>
+struct RowStream {
+    static_assert(sizeof(V) == 8, "64-bit words");
+    __amdgpu_buffer_rsrc_t rsrc;
+    // (the base is wave-uniform by construction; saying so keeps the compiler from wrapping every load in a
+    // "waterfall" loop over the distinct descriptors of a wave)
+    __device__ __forceinline__ static V* uniform(const V* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const u32 lo = __builtin_amdgcn_readfirstlane(u32(v)), hi = __builtin_amdgcn_readfirstlane(u32(v >> 32));
+        return (V*)(((unsigned long long)hi << 32) | lo);
+    }
+    __device__ __forceinline__ RowStream(const V* base, u32 bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(uniform(base), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ V at(u32 thread_byte_offset, u32 row_byte_offset) const {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)thread_byte_offset, (int)row_byte_offset, 0);
+        V d;
+        __builtin_memcpy(&d, &x, 8);
+        return d;
+    }
+};
+
 template <int LOGN, int LOGE>
 struct Geom {
     static constexpr int N = 1 << LOGN;

@@ -73,6 +73,19 @@ def test_every_arithmetic_path(hx, ctx, dev, orc, monkeypatch, which):
         assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"{which} instance {b}"
 
 
+@pytest.mark.parametrize("n,L,K,bits", [(1024, 1, 2, 55), (1024, 3, 4, 59), (2048, 2, 3, 57), (4096, 5, 7, 55), (8192, 6, 7, 59),
+                                        (16384, 6, 7, 55), (16384, 7, 8, 59), (16384, 15, 16, 53)])
+def test_integer_kernels_every_size(hx, ctx, dev, orc, n, L, K, bits):
+    """moduli >= 2^52 select the 64-bit integer kernels (keyswitch.hip, second generation: k_ks_intt / k_ksi_special /
+    k_ksi_main) at every ring dimension the API accepts for them"""
+    case = KsCase(orc, n, L, K, seed=n + L + bits, bits=bits)
+    nb = 3 if n >= 8192 else 5
+    ts, rs = zip(*[case.inputs(orc, b) for b in range(nb)])
+    got = run_gpu(hx, ctx, dev, case, ts, rs)
+    for b in range(nb):
+        assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"instance {b}"
+
+
 def test_caller_twiddles_honoured(hx, ctx, dev, orc):
     """twiddle_factors != nullptr path (tests/test_keyswitch.cpp:73-90 passes the 4-block table)"""
     case = KsCase(orc, 4096, 3, 4, seed=11, with_twiddles=True)
@@ -285,8 +298,11 @@ except hx.HexlError as e:
 
 
 @pytest.mark.parametrize("env", [{"HEXL_KS_PIPE": "1"}, {"HEXL_KSX_LOGE": "5", "HEXL_KS_PIPE": "3"}, {"HEXL_KSX_PERSIST": "0"},
-                                 {"HEXL_KS_ONE_LANE": "1"}],
-                         ids=["bd_major_pipeline", "slot_major_32x512", "slot_major_one_item_per_workgroup", "one_lane"])
+                                 {"HEXL_KS_ONE_LANE": "1"}, {"HEXL_KS_INT": "1"}, {"HEXL_KS_INT": "1", "HEXL_KS_PIPE": "1"},
+                                 {"HEXL_KS_INT": "1", "HEXL_KSI_LOGE": "4"},
+                                 {"HEXL_KS_INT": "1", "HEXL_KSI_LOGE": "4", "HEXL_KS_PIPE": "1"}],
+                         ids=["bd_major_pipeline", "slot_major_32x512", "slot_major_one_item_per_workgroup", "one_lane",
+                              "integer_kernels", "integer_first_generation", "integer_16x1024", "integer_first_generation_16x1024"])
 def test_alternative_pipelines_agree_with_the_oracle(env):
     """the kernels the default no longer selects for a large N = 16384 batch -- the (b, d)-major pipeline of round 1
     (k_ksf_up / k_ksf_mac / ...), the 32 x 512 geometry of the slot-major one, its non-persistent grids, a single lane --
