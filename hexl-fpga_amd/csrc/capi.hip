@@ -241,7 +241,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         HX_CHECK(hipMalloc((void**)&p->d_mods_f64, K * sizeof(KsModF64)));
         HX_CHECK(hipMalloc((void**)&p->d_tables_f64, ft.size() * sizeof(double)));
         HX_CHECK(hipMalloc((void**)&p->d_keys_f64, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
-        if (logn == 14) HX_CHECK(hipMalloc((void**)&p->d_keys_x, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
+        if (logn >= 10 && logn <= 14) HX_CHECK(hipMalloc((void**)&p->d_keys_x, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
         HX_CHECK(hipMemcpy(p->d_mods_f64, fm.data(), K * sizeof(KsModF64), hipMemcpyHostToDevice));
         HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -287,7 +287,7 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     std::vector<double> devf, devx;
     std::vector<u32> permf, permx;
     if (p->use_f64) { devf.resize(dev.size()); permf = ks_perm(p->logn, p->f64_loge); }
-    if (p->d_keys_x) { devx.resize(dev.size()); p->x_loge = hx_ks_x_loge(); permx = ks_perm(p->logn, p->x_loge); }
+    if (p->d_keys_x) { devx.resize(dev.size()); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
     for (u64 d = 0; d < L; ++d) {
         if (!h_keys[d]) return HEXL_E_BADARG;
         for (u64 slot = 0; slot <= L; ++slot) {

@@ -394,13 +394,16 @@ static int run_chunk(hexl_ks_plan* p, const KsArgs& a, int stage_mask, hipEvent_
     return (int)hipGetLastError();
 }
 
-static size_t ks_chunk_default() {
+// instances per scratch chunk: HEXL_KS_CHUNK, else 256 at N = 16384 and the same number of COEFFICIENTS per chunk at the
+// other ring dimensions (4096 instances at N = 1024: a chunk's kernels must fill the chip whatever the transform size)
+static size_t ks_chunk_default(const hexl_ks_plan* p) {
     static const long v = [] {
         const char* e = getenv("HEXL_KS_CHUNK");
-        const long c = e ? atol(e) : 256;
-        return c < 1 ? 1L : c;
+        const long c = e ? atol(e) : 0;
+        return c < 0 ? 0L : c;
     }();
-    return (size_t)v;
+    if (v) return (size_t)v;
+    return p->logn >= 14 ? size_t(256) >> (p->logn - 14) : size_t(256) << (14 - p->logn);
 }
 
 size_t hx_ks_f64_scratch_words(size_t L);
@@ -408,7 +411,7 @@ static size_t scratch_words(const hexl_ks_plan* p) {           // per instance, 
     return p->use_f64 ? hx_ks_f64_scratch_words(p->L) : size_t(3) * p->L + 2;
 }
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
-    const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    const size_t chunk = batch < ks_chunk_default(p) ? batch : ks_chunk_default(p);
     return 2 * chunk * scratch_words(p) * p->n * sizeof(u64);      // two lanes
 }
 
@@ -447,7 +450,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         if (int rc = validate_inputs(p, d_result, d_t_target, batch)) return rc;
     // chunks alternate between two lanes; a batch that fits one chunk is still split in two when it is large
     // enough to fill the chip twice, so the lanes always have something to overlap. Timing runs (ev) stay on one lane.
-    size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    size_t chunk = batch < ks_chunk_default(p) ? batch : ks_chunk_default(p);
     // (FP64 path: with one barrier per transform and steps 1-2 fused, two lanes measure the same as one stream
     // (160 k vs 162 k keyswitch/s), so it runs its chunks back to back on the caller's stream; HEXL_KS_ONE_LANE=0
     // brings the lanes back)
@@ -533,7 +536,7 @@ int hx_launch_multiply_relinearize(hexl_ks_plan* p, u64* d_out, const u64* d_a, 
     if (!batch) return 0;
     if (!p->have_keys) return HEXL_E_NOKEYS;
     if (!p->use_f64 || p->logn != 14) return HEXL_E_BADARG;
-    const size_t chunk = batch < ks_chunk_default() ? batch : ks_chunk_default();
+    const size_t chunk = batch < ks_chunk_default(p) ? batch : ks_chunk_default(p);
     const size_t lane_words = chunk * scratch_words(p) * p->n;
     if (p->cap < chunk) {
         if (p->d_scratch) { HX_CHECK(hipDeviceSynchronize()); HX_CHECK(hipFree(p->d_scratch)); }

@@ -40,6 +40,10 @@ using namespace hx;
 #define KX_SLOT_MAJOR 0
 #endif
 
+// 16 coefficients per thread: the kernels are written for 128 VGPRs = four waves per SIMD, which a 1024-thread workgroup
+// (N = 16384) implies and the smaller ring dimensions (512 ... 64 threads, several workgroups per CU) have to ask for
+#define KX_WAVES(LOGE) ((LOGE) == 4 ? 4 : 2)
+
 struct KsArgsX {
     const KsModF64* mods;    // [K]
     const double* tables;    // [K][4][n]: w, w/p, inverse w (first entry at index 1), inverse w/p
@@ -178,7 +182,7 @@ __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __re
 // accumulators, and every reload inside the multiply-accumulate waits for the whole key prefetch queue -- vector
 // memory returns in order. That version spent 42 k cycles per multiply-accumulate instead of 10 k.)
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
-__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
+__global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, 0>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_intt(KsArgsX a) {
 // steps 2-4 for the special slot of one instance: acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k], then
 // s'_k = INTT_{q_sp}(acc_k) + floor(q_sp/2)
 template <int LOGN, int LOGE, int LAZY>
-__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_special(KsArgsX a) {
+__global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
@@ -365,7 +369,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
 }
 
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
-__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksx_main(KsArgsX a) {
+__global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
@@ -480,9 +484,11 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
     // persistent grids: 8 x g workgroups, g = workgroups per XCD = one per CU unless there are fewer items
     // (HEXL_KSX_PERSIST=0: one workgroup per item)
     static const int persist = [] { const char* e = getenv("HEXL_KSX_PERSIST"); return e ? atoi(e) : 1; }();
+    // workgroups one CU holds at once: 16 (or 8) waves of 64 threads
+    constexpr u32 wg_per_cu = (KX_WAVES(LOGE) * 4 * 64) / G::T ? (KX_WAVES(LOGE) * 4 * 64) / G::T : 1;
     auto grid_for = [&](u32 items) {
-        const u32 per_xcd = (items + 7) / 8, cu_per_xcd = ((u32)p->ctx->num_cu + 7) / 8;
-        return dim3(8 * (persist && per_xcd > cu_per_xcd ? cu_per_xcd : per_xcd));
+        const u32 per_xcd = (items + 7) / 8, slots = (((u32)p->ctx->num_cu + 7) / 8) * wg_per_cu;
+        return dim3(8 * (persist && per_xcd > slots ? slots : per_xcd));
     };
     if (stage_mask & 1)
         hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY, FUSED>), grid_for(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
@@ -506,8 +512,15 @@ u32 hx_ks_x_loge() {                                              // HEXL_KSX_LO
 }
 bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
     static const int pipe = [] { const char* e = getenv("HEXL_KS_PIPE"); return e ? atoi(e) : 2; }();
-    if (!p->d_keys_x || p->logn != 14) return false;
-    return pipe == 3 || (pipe == 2 && nb * p->L >= 2 * (size_t)p->ctx->num_cu);      // 3: always (tests)
+    if (!p->d_keys_x || p->logn < 10 || p->logn > 14) return false;
+    // one workgroup per (instance, limb) must fill the chip at least twice (a CU holds 16384 / N of them)
+    return pipe == 3 || (pipe == 2 && ((nb * p->L) << p->logn) >= ((2 * (size_t)p->ctx->num_cu) << 14));      // 3: always (tests)
+}
+
+template <int LOGN>
+static int launch_x_small(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
+    // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
+    return p->f64_lazy ? run_chunk_x<LOGN, 4, 3>(p, a, stage_mask, ev) : run_chunk_x<LOGN, 4, 0>(p, a, stage_mask, ev);
 }
 
 int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
@@ -521,7 +534,14 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = a.mul_b = nullptr;
     a.stamps = nullptr;
-    if (p->logn != 14) return HEXL_E_BADARG;
+    switch (p->logn) {
+        case 10: return launch_x_small<10>(p, a, stage_mask, ev);
+        case 11: return launch_x_small<11>(p, a, stage_mask, ev);
+        case 12: return launch_x_small<12>(p, a, stage_mask, ev);
+        case 13: return launch_x_small<13>(p, a, stage_mask, ev);
+        case 14: break;
+        default: return HEXL_E_BADARG;
+    }
     // LAZY template argument = forward reduction period of the transforms (f64_arith.hpp), as in keyswitch_f64.hip
     if (p->x_loge == 5)                                           // 32 coefficients x 512 threads: measured slower, kept for study
         return p->f64_lazy ? run_chunk_x<14, 5, 3>(p, a, stage_mask, ev) : run_chunk_x<14, 5, 0>(p, a, stage_mask, ev);

@@ -86,6 +86,26 @@ def test_integer_kernels_every_size(hx, ctx, dev, orc, n, L, K, bits):
         assert np.array_equal(got[b], case.expected(orc, ts[b], rs[b])), f"instance {b}"
 
 
+@pytest.mark.parametrize("n,L,K", [(1024, 3, 4), (2048, 6, 7), (4096, 2, 3), (8192, 3, 4)])
+def test_large_batches_of_small_rings(hx, ctx, dev, orc, n, L, K):
+    """batches large enough for the slot-major pipeline at N < 16384 (one workgroup per (instance, limb) has to fill the
+    chip twice: keyswitch_x.hip hx_ks_x_applies) and for more than one scratch chunk (256 * 16384 / N instances)"""
+    case = KsCase(orc, n, L, K, seed=3 * n + L)
+    nb = 2 * 256 * 16384 // (n * L) + 256 * 16384 // n + 37
+    ins = [case.inputs(orc, b) for b in range(4)]
+    d_t = hx.as_i64(np.concatenate([ins[b % 4][0] for b in range(nb)])).to(dev)
+    d_r = hx.as_i64(np.concatenate([ins[b % 4][1] for b in range(nb)])).to(dev)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    plan.keyswitch(d_r, d_t, nb)
+    ctx.sync()
+    out = hx.to_u64(d_r).reshape(nb, -1)
+    plan.close()
+    for j in range(4):
+        want = case.expected(orc, *ins[j])
+        assert (out[j::4] == want).all(), f"instances {j} mod 4"
+
+
 def test_caller_twiddles_honoured(hx, ctx, dev, orc):
     """twiddle_factors != nullptr path (tests/test_keyswitch.cpp:73-90 passes the 4-block table)"""
     case = KsCase(orc, 4096, 3, 4, seed=11, with_twiddles=True)
@@ -305,8 +325,20 @@ except hx.HexlError as e:
                               "integer_kernels", "integer_first_generation", "integer_16x1024", "integer_first_generation_16x1024"])
 def test_alternative_pipelines_agree_with_the_oracle(env):
     """the kernels the default no longer selects for a large N = 16384 batch -- the (b, d)-major pipeline of round 1
-    (k_ksf_up / k_ksf_mac / ...), the 32 x 512 geometry of the slot-major one, its non-persistent grids, a single lane --
+    (k_ksf_up / k_ksf_mac / ...), the 32 x 512 geometry of the slot-major one, its non-persistent grids, a single lane,
+    the integer kernels in both generations and geometries --
     must still give the oracle's bits (the knobs are read once per process, hence a child process each)"""
+    _alternative(env, 16384, 6, 7, 300)
+
+
+@pytest.mark.parametrize("n,nb", [(1024, 9000), (4096, 2200), (8192, 1100)])
+def test_bd_major_pipeline_on_small_rings(n, nb):
+    """HEXL_KS_PIPE=1 at N < 16384: the (b, d)-major kernels on batches the slot-major pipeline now takes by default"""
+    _alternative({"HEXL_KS_PIPE": "1"}, n, 3, 4, nb)
+
+
+def _alternative(env, n, L, K, nb):
+    """`nb` instances (three distinct ones repeated) through the library in a child process with `env` set, against the oracle"""
     import os
     import subprocess
     import sys
@@ -316,7 +348,7 @@ sys.path[:0] = [%r, %r, %r]
 import numpy as np, torch, hexl_fpga_amd as hx, orc
 from ks_util import KsCase
 dev = torch.device("cuda:0"); ctx = hx.Context(0)
-n, L, K, nb = 16384, 6, 7, 300
+n, L, K, nb = %d, %d, %d, %d
 case = KsCase(orc, n, L, K, seed=77)
 plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
 ins = [case.inputs(orc, b) for b in range(3)]
@@ -326,7 +358,7 @@ plan.keyswitch(d_r, d_t, nb); ctx.sync()
 out = hx.to_u64(d_r).reshape(nb, -1)
 want = [case.expected(orc, t, r) for t, r in ins]
 print("OK" if all(np.array_equal(out[b], want[b %% 3]) for b in range(nb)) else "MISMATCH")
-''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"))
+''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"), n, L, K, nb)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     print(out.stdout[-500:], out.stderr[-1500:])
     assert out.returncode == 0 and out.stdout.strip().endswith("OK")
