@@ -413,14 +413,27 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     return (int)hipGetLastError();
 }
 
+// FP64 transforms of N = 2048 .. 8192: 16 coefficients per thread where that measured faster than 32 (twice the waves
+// per CU, but a different run length per lane in the B-order access): forward N = 2048 (+17 %) and 8192 (+16 %), inverse
+// N = 2048 (+12 %); N = 4096 lost 16 % both ways, the inverse at 8192 11 % (tools/ntt_n_sweep.py).
+// HEXL_NTT_E16 = bit mask over logn - 11 forces the choice for both directions.
+static bool small_e16(int logn, bool fwd) {
+    static const int mask = [] { const char* e = getenv("HEXL_NTT_E16"); return e ? atoi(e) : -1; }();
+    const int m = mask >= 0 ? mask : (fwd ? 0b101 : 0b001);
+    return (m >> (logn - 11)) & 1;
+}
+
 template <int LAZY>
 static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, const double* w,
                           const double* wp, const u32* v) {
     switch (logn) {
         case 10: return launch_fwd_x<10, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 11: return launch_fwd_x<11, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 12: return launch_fwd_x<12, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 13: return launch_fwd_x<13, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 11: return small_e16(11, true) ? launch_fwd_x<11, 4, LAZY>(c, x, batch, r, p, q, w, wp, v)
+                                   : launch_fwd_x<11, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 12: return small_e16(12, true) ? launch_fwd_x<12, 4, LAZY>(c, x, batch, r, p, q, w, wp, v)
+                                   : launch_fwd_x<12, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
+        case 13: return small_e16(13, true) ? launch_fwd_x<13, 4, LAZY>(c, x, batch, r, p, q, w, wp, v)
+                                   : launch_fwd_x<13, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
         case 14: return launch_fwd_x<14, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
         case 15: return launch_fwd_x<15, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);    // beyond the reference: half-size exchanges
         default: return HEXL_E_BADARG;
@@ -431,9 +444,12 @@ static int dispatch_inv_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64
                           u64 b, u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* v) {
     switch (logn) {
         case 10: return launch_inv_x<10, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 11: return launch_inv_x<11, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 12: return launch_inv_x<12, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 13: return launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 11: return small_e16(11, false) ? launch_inv_x<11, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v)
+                                   : launch_inv_x<11, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 12: return small_e16(12, false) ? launch_inv_x<12, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v)
+                                   : launch_inv_x<12, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 13: return small_e16(13, false) ? launch_inv_x<13, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v)
+                                   : launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
         case 14: return launch_inv_x<14, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
         case 15: return launch_inv_x<15, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
         default: return HEXL_E_BADARG;

@@ -131,3 +131,41 @@ def test_n32768_beyond_the_reference_envelope(hx, ctx, dev, orc, bits):
     ctx.ntt_inv(d, tabs[2], tabs[3], q, tb.inv_n, tb.inv_n_w, n)
     ctx.sync()
     assert np.array_equal(hx.to_u64(d), orc.ntt_inv(ys, tb))
+
+
+@pytest.mark.parametrize("env", [{"HEXL_NTT_E16": "7"}, {"HEXL_NTT_E16": "0"}, {"HEXL_NTT_INT": "1"}, {"HEXL_NTT_PERSIST": "0"}],
+                         ids=["fp64_16_per_thread", "fp64_32_per_thread", "integer_butterflies", "one_workgroup_per_polynomial"])
+def test_alternative_geometries_agree_with_the_oracle(env):
+    """the kernel variants the defaults do not select at some ring dimension (ntt.hip small_e16, HEXL_NTT_INT,
+    HEXL_NTT_PERSIST; knobs are read once per process, hence a child process): N = 2048 .. 16384, batches large
+    enough for the persistent kernels, forward and inverse against the oracle"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+dev = torch.device("cuda:0"); ctx = hx.Context(0)
+ok = True
+for n in (2048, 4096, 8192, 16384):
+    q = orc.primes(2, 51, n)[1]
+    t = orc.HexlTables(n, q)
+    x = np.stack([orc.splitmix(n, 7 + b, q) for b in range(4)])
+    batch = 3000 * 2048 // n + 5
+    tabs = [hx.as_i64(a).to(dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
+    for fwd in (True, False):
+        d = hx.as_i64(x).to(dev).repeat((batch + 3) // 4, 1)[:batch].contiguous()
+        if fwd: ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)
+        else: ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
+        ctx.sync()
+        got = hx.to_u64(d).reshape(batch, n)
+        want = orc.ntt_fwd(x, t) if fwd else orc.ntt_inv(x, t)
+        ok = ok and all((got[j::4] == want[j]).all() for j in range(4))
+print("OK" if ok else "MISMATCH")
+''' % (str(root), str(root / "oracle"), str(root / "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    print(out.stdout[-500:], out.stderr[-1500:])
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK")
