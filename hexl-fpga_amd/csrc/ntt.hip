@@ -137,6 +137,34 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
     }
 }
 
+// "Did any thread of the workgroup see an out-of-range word?" without a barrier of its own. A __syncthreads_or behind
+// the transform holds every wave until the slowest has finished, once per polynomial; the ballot is known BEFORE the
+// transform, and every transform of a multi-wave workgroup contains a cross-wave re-deal with a barrier between its
+// writes and reads (a one-wave workgroup executes its LDS operations in order): a flag set in LDS before the transform is
+// therefore visible to every wave behind it. Three flags rotate so that the reset of a flag (by thread 0, behind the
+// transform of round k: the flag of round k - 1, whose readers have all passed round k's barrier) is separated by round
+// k + 1's barrier from its next setters in round k + 2. All waves take the same decision, and take it before any of
+// them stores (the fallback re-reads the input, which is overwritten in place).
+struct RangeVote {
+    u32* flags;
+    u32 k;
+    static constexpr size_t BYTES = 16;
+    __device__ __forceinline__ explicit RangeVote(char* at) : flags(reinterpret_cast<u32*>(at)), k(0) {
+        if (threadIdx.x < 3) flags[threadIdx.x] = 0;
+        __syncthreads();                                          // once per kernel
+    }
+    __device__ __forceinline__ void cast(bool bad) {
+        if (bad) flags[k] = 1;
+    }
+    __device__ __forceinline__ bool result(int tid) {            // call behind the transform
+        const bool bad = flags[k] != 0;
+        const u32 prev = k == 0 ? 2 : k - 1;
+        if (tid == 0) flags[prev] = 0;
+        k = k == 2 ? 0 : k + 1;
+        return bad;
+    }
+};
+
 // Persistent variants (the default fast path): one workgroup per CU walks the batch, and the NEXT polynomial's words
 // are requested into 2 E spare registers at the very start of the current transform. A lone 1024-thread workgroup per
 // CU otherwise waits ~5 us for its 128 KiB input before every ~13 us transform (tools/ntt_timeline.hip) and pays the
@@ -155,6 +183,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
     const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
     const Mod m{(double)q, 1.0 / (double)q};
     const bool bad_tables = *violations != 0;
+    RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
     u64 raw[G::E];
     {
         const int tid = threadIdx.x;
@@ -174,12 +203,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
             out_of_range |= raw[r] >= limit;
             f[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
         }
+        vote.cast(out_of_range);
         const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;                // (last round: a harmless re-read)
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
         WgNttF64<LOGN, LOGE, LAZY>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
-        const bool slow = __syncthreads_or(out_of_range) || bad_tables;          // see k_ntt_fwd_x
+        const bool slow = vote.result(tid) || bad_tables;                        // see k_ntt_fwd_x, RangeVote
         if (!slow) {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
@@ -202,6 +232,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
     const Mod m{(double)q, 1.0 / (double)q};
     const bool bad_tables = *violations != 0;
+    RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
     u64 raw[G::E];
     {
         const int tid = threadIdx.x;
@@ -222,6 +253,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
             out_of_range |= raw[r] >= limit;
             f[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
         }
+        vote.cast(out_of_range);
         // the inverse starts with its per-lane twiddle pass: the next input is requested behind that pass's twiddles,
         // i.e. after the first (wave-private) re-deal -- the following passes use the scalar cache
         const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 #pragma unroll
             for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
         });
-        const bool slow = __syncthreads_or(out_of_range) || bad_tables;
+        const bool slow = vote.result(tid) || bad_tables;
         if (!slow) {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
@@ -372,11 +404,11 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
     if (persist && !G::HALF_ONLY && batch > slots) {
         static PerDeviceOnce once_p;
         if (int rc = once_p.run(ctx->device, [] {
-                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_USED + RangeVote::BYTES)));
                 return 0;
             }))
             return rc;
-        hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x,
+        hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
                            roots, precon, q, w, wp, viol, (u32)batch);
         return (int)hipGetLastError();
     }
@@ -400,11 +432,11 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     if (persist && !G::HALF_ONLY && batch > slots) {
         static PerDeviceOnce once_p;
         if (int rc = once_p.run(ctx->device, [] {
-                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_USED + RangeVote::BYTES)));
                 return 0;
             }))
             return rc;
-        hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x,
+        hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
                            ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
         return (int)hipGetLastError();
     }

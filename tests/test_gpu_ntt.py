@@ -169,3 +169,28 @@ print("OK" if ok else "MISMATCH")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     print(out.stdout[-500:], out.stderr[-1500:])
     assert out.returncode == 0 and out.stdout.strip().endswith("OK")
+
+
+@pytest.mark.parametrize("n", [1024, 4096, 16384])
+def test_out_of_range_polynomials_inside_a_persistent_batch(hx, ctx, dev, orc, n):
+    """a batch large enough for the persistent FP64 kernels in which every seventh polynomial carries ONE word outside the
+    Harvey input range (at a different position each time): exactly those take the integer fallback (ntt.hip RangeVote),
+    their neighbours the FP64 path, and all of them match the oracle's op-for-op replay"""
+    q = orc.primes(1, 51, n)[0]
+    t = orc.HexlTables(n, q)
+    batch = 5000 * 1024 // n + 3
+    base = np.stack([orc.splitmix(n, 50 + b, q) for b in range(3)])
+    x = base[np.arange(batch) % 3].copy()
+    bad = np.arange(3, batch, 7)
+    pos = (bad * 2654435761) % n
+    x[bad, pos] = np.uint64((1 << 63) + 5) + bad.astype(np.uint64)
+    distinct = {}
+    for fwd in (True, False):
+        got = (run_fwd if fwd else run_inv)(hx, ctx, dev, x, t)
+        ref3 = (orc.ntt_fwd if fwd else orc.ntt_inv)(base, t)
+        clean = np.setdiff1d(np.arange(batch), bad)
+        assert (got[clean] == ref3[clean % 3]).all()
+        sample = bad[:: max(1, len(bad) // 24)]                    # the oracle is slow: a spread of the dirty ones
+        want = (orc.ntt_fwd if fwd else orc.ntt_inv)(x[sample], t)
+        assert np.array_equal(got[sample], want)
+        distinct[fwd] = got
