@@ -260,11 +260,11 @@ def main():
         if not a.no_extra:
             extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
-            def other_shape(Lx, Kx, moduli=None):
-                cs = KsCase(orc_mod, N, Lx, Kx, seed=99, moduli=moduli)
-                pl = hx.KeySwitchPlan(ctx, N, Lx, Kx, Kx, 2, cs.moduli, cs.modswitch)
+            def other_shape(Lx, Kx, moduli=None, n=N):
+                cs = KsCase(orc_mod, n, Lx, Kx, seed=99, moduli=moduli)
+                pl = hx.KeySwitchPlan(ctx, n, Lx, Kx, Kx, 2, cs.moduli, cs.modswitch)
                 pl.set_keys(cs.keys)
-                nbx = min(a.batch, 2048)
+                nbx = min(a.batch, 2048) * (N // n)
                 tx, rx = device_inputs(hx, orc_mod, cs, nbx, dev)
                 pl.keyswitch(rx, tx, nbx)
                 torch.cuda.synchronize()
@@ -277,7 +277,7 @@ def main():
                 ms = f0.elapsed_time(f1) / 3
                 pl.close()
                 return {"keyswitches_per_s": nbx / (ms * 1e-3), "batch": nbx,
-                        "alg_GBps": ks_alg_bytes(N, Lx) * nbx / (ms * 1e-3) / 1e9}
+                        "alg_GBps": ks_alg_bytes(n, Lx) * nbx / (ms * 1e-3) / 1e9}
             # ciphertext multiply + relinearize: DyadicMultiply then KeySwitch as two primitives vs the fused pass
             def mulrelin():
                 nbx = min(a.batch, 2048)
@@ -316,6 +316,9 @@ def main():
             extra["keyswitch_16384_6_7_7_2"] = other_shape(6, 7)
             # the same shape with 48-bit primes (SEAL's default parameter sizes for N=16384): longer lazy-reduction period
             extra["keyswitch_16384_6_7_7_2_48bit_primes"] = other_shape(6, 7, orc_mod.primes(7, 48, N))
+            # the smaller ring dimensions the reference's KeySwitch accepts (host/src/keyswitch.cpp:23-25), decomp 3 / 4 key moduli
+            for nx in (8192, 4096, 1024):
+                extra["keyswitch_%d_3_4_4_2" % nx] = other_shape(3, 4, None, nx)
             # the headline shape on the 64-bit INTEGER kernels (59-bit primes: beyond the reference's < 2^52 envelope)
             extra["keyswitch_16384_L%d_59bit_primes_integer_kernels" % L] = other_shape(L, L + 1, orc_mod.primes(L + 1, 59, N))
         out["extra"] = extra
