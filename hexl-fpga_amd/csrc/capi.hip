@@ -247,7 +247,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
     }
     HX_CHECK(hipMalloc((void**)&p->d_mods, K * sizeof(KsModulus)));
     HX_CHECK(hipMalloc((void**)&p->d_tables, tables.size() * sizeof(u64)));
-    HX_CHECK(hipMalloc((void**)&p->d_keys, size_t(L) * (L + 1) * 2 * n * sizeof(u64)));
+    HX_CHECK(hipMalloc((void**)&p->d_keys, size_t(L) * (L + 1) * 4 * n * sizeof(u64)));     // key words + Shoup factors
     HX_CHECK(hipMemcpy(p->d_mods, mods.data(), K * sizeof(KsModulus), hipMemcpyHostToDevice));
     HX_CHECK(hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(u64), hipMemcpyHostToDevice));
     *out = p;
@@ -283,11 +283,12 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     HX_CHECK(hipSetDevice(p->ctx->device));
     const u64 n = p->n, L = p->L, K = p->K;
     const std::vector<u32> perm = ks_perm(p->logn, p->int_loge);
-    std::vector<u64> dev(size_t(L) * (L + 1) * 2 * n);
+    // integer kernels: [d][slot][k][0] = key mod q, [..][1] = floor(that * 2^64 / q) (only computed when they can run)
+    std::vector<u64> dev(size_t(L) * (L + 1) * 4 * n);
     std::vector<double> devf, devx;
     std::vector<u32> permf, permx;
-    if (p->use_f64) { devf.resize(dev.size()); permf = ks_perm(p->logn, p->f64_loge); }
-    if (p->d_keys_x) { devx.resize(dev.size()); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
+    if (p->use_f64) { devf.resize(dev.size() / 2); permf = ks_perm(p->logn, p->f64_loge); }
+    if (p->d_keys_x) { devx.resize(dev.size() / 2); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
     for (u64 d = 0; d < L; ++d) {
         if (!h_keys[d]) return HEXL_E_BADARG;
         for (u64 slot = 0; slot <= L; ++slot) {
@@ -296,7 +297,11 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
             for (u64 k = 0; k < 2; ++k) {
                 const u64* src = h_keys[d] + (k * K + i) * n;            // fpga.cpp:1186-1190
                 const size_t base = ((d * (L + 1) + slot) * 2 + k) * n;
-                for (u64 j = 0; j < n; ++j) dev[base + j] = src[perm[j]];
+                for (u64 j = 0; j < n; ++j) {
+                    const u64 v = src[perm[j]] % q;
+                    dev[2 * base + j] = v;
+                    if (!p->use_f64) dev[2 * base + n + j] = (u64)(((u128)v << 64) / q);
+                }
                 if (p->use_f64)                                          // same limb as centred doubles
                     for (u64 j = 0; j < n; ++j) {
                         const u64 v = src[permf[j]] % q;

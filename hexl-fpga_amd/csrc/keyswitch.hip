@@ -43,7 +43,7 @@ __device__ __forceinline__ u32 xcd_item(u32 bid, u32 total) {
 struct KsArgs {
     const KsModulus* mods;   // [K]
     const u64* tables;       // [K][4][n]
-    const u64* keys;         // [L][L+1][2][n]  B order
+    const u64* keys;         // [L][L+1][2][2][n]  B order; [..][k][0] = key mod q, [..][k][1] = its Shoup factor floor(key 2^64 / q)
     u64* c;                  // [chunk][L][n]      natural order
     u64* prod;               // [chunk][2][L][n]   B order
     u64* s;                  // [chunk][2][n]      natural order
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_modup(KsArgs a) {
         const u64* roots = tb + opaque_zero();          // keep twiddle loads inside the d loop
         W::forward_lazy(v, lds, tid, roots, roots + G::N, q);
         W::final_reduce(v, q);
-        const u64* k0 = a.keys + ((size_t(d) * (L + 1) + slot) * 2) * G::N;
-        const u64* k1 = k0 + G::N;
+        const u64* k0 = a.keys + ((size_t(d) * (L + 1) + slot) * 4) * G::N;
+        const u64* k1 = k0 + 2 * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) {                 // dyadmult.hpp:128-140
             const u64 key0 = k0[r * G::T + tid], key1 = k1[r * G::T + tid];
@@ -174,31 +174,47 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_moddown(KsArgs a) {
 //   k_ksi_main    (b, i<L)  acc_k = sum_d NTT_{q_i}(c_d mod q_i) . key[d][i][k]; then for k = 0, 1:
 //                           w = NTT_{q_i}((s'_k + fix_i) mod q_i);  result[k][i] += (acc_k - w) . msf_i
 
-// acc_k += v . key_k (dyadmult.hpp:128-140); v[r] is replaced by word r of `next` (A order, never null)
+// acc_k += v . key_k (dyadmult.hpp:128-140); v[r] is replaced by word r of `next` (A order, never null).
+// The keys carry their Shoup factors (computed once per key set on the host), so a term is one Harvey lazy product --
+// ~20 VALU instructions against ~50 for the 128 -> 64-bit Barrett product of the first generation -- and takes the
+// transform's output as it is (v < 4q; lazy_mul_n accepts any 64-bit x and returns < 2q). The accumulators stay in [0, 2q).
 template <class G>
 __device__ __forceinline__ void mac_keys_i(u64 (&acc0)[G::E], u64 (&acc1)[G::E], u64 (&v)[G::E], const u64* __restrict__ k0,
                                            const u64* __restrict__ next, int tid, const KsModulus& md) {
 #ifndef KSI_PF32
-#define KSI_PF32 8
-#define KSI_PF16 4
+#define KSI_PF32 4
+#define KSI_PF16 2
 #endif
     constexpr int PF = G::E >= 32 ? KSI_PF32 : KSI_PF16;
-    const RowStream<u64> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
-    const u32 toff = u32(tid) * 8, len = u32(md.len);
-    const u64 q = md.q;
-    u64 ka[PF], kb[PF];
+    const RowStream<u64> keys(k0, 4 * G::N * 8), nxt(next, G::N * 8);
+    const u32 toff = u32(tid) * 8;
+    const ModConst mc = mod_const(md.q);
+    u64 ka[PF], kap[PF], kb[PF], kbp[PF];
 #pragma unroll
-    for (int r = 0; r < PF; ++r) { ka[r] = keys.at(toff, r * G::T * 8); kb[r] = keys.at(toff, (G::N + r * G::T) * 8); }
+    for (int r = 0; r < PF; ++r) {
+        ka[r] = keys.at(toff, r * G::T * 8);                 kap[r] = keys.at(toff, (G::N + r * G::T) * 8);
+        kb[r] = keys.at(toff, (2 * G::N + r * G::T) * 8);    kbp[r] = keys.at(toff, (3 * G::N + r * G::T) * 8);
+    }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
-        const u64 ca = ka[r % PF], cb = kb[r % PF];
-        if (r + PF < G::E) { ka[r % PF] = keys.at(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.at(toff, (G::N + (r + PF) * G::T) * 8); }
+        const u64 ca = ka[r % PF], cap = kap[r % PF], cb = kb[r % PF], cbp = kbp[r % PF];
+        if (r + PF < G::E) {
+            ka[r % PF] = keys.at(toff, (r + PF) * G::T * 8);                kap[r % PF] = keys.at(toff, (G::N + (r + PF) * G::T) * 8);
+            kb[r % PF] = keys.at(toff, (2 * G::N + (r + PF) * G::T) * 8);   kbp[r % PF] = keys.at(toff, (3 * G::N + (r + PF) * G::T) * 8);
+        }
         const u64 x = v[r];
         v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
-        acc0[r] = csub(acc0[r] + mulmod128(x, ca, q, len, md.barr_lo), q);
-        acc1[r] = csub(acc1[r] + mulmod128(x, cb, q, len, md.barr_lo), q);
+        acc0[r] = csub_n(acc0[r] + lazy_mul_n(x, ca, cap, mc.nq), mc.twoq, mc.n2q);
+        acc1[r] = csub_n(acc1[r] + lazy_mul_n(x, cb, cbp, mc.nq), mc.twoq, mc.n2q);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+// accumulators of mac_keys_i back to [0, q)
+template <int E>
+__device__ __forceinline__ void canonical(u64 (&acc)[E], u64 q) {
+    const ModConst mc = mod_const(q);
+#pragma unroll
+    for (int r = 0; r < E; ++r) acc[r] = csub_n(acc[r], q, mc.nq);
 }
 
 template <int LOGN, int LOGE>
@@ -223,11 +239,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_special(KsArgs a) {
         const u64* ts = a.tables + size_t(isp) * 4 * G::N + opaque_zero();
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = barrett64(v[r], q, md.qbarr);             // intt1_redu.hpp:36-42
-        W::forward_lazy(v, lds, tid, ts, ts + G::N, q);
-        W::final_reduce(v, q);
+        W::forward_lazy(v, lds, tid, ts, ts + G::N, q);            // v < 4q
         const u32 nd = d + 1 < L ? d + 1 : d;                     // (the last limb is requested twice: harmless)
-        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(d) * (L + 1) + L) * 2) * G::N, a.c + (size_t(b) * L + nd) * G::N, tid, md);
+        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(d) * (L + 1) + L) * 4) * G::N, a.c + (size_t(b) * L + nd) * G::N, tid, md);
     }
+    canonical(acc0, q);
+    canonical(acc1, q);
     // s'_k = INTT(acc_k) + floor(q_sp/2) (mod q_sp)   (intt2_redu.hpp:25,43)
     {
         int tid = threadIdx.x;
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_main(KsArgs a) {
         const u32 tB = u32(G::idxB(0, tid));
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = barrett64((src + G::idxB(r, 0))[tB], q, md.qbarr);
-        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N, round_src(first), tid, md);
+        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(i) * (L + 1) + i) * 4) * G::N, round_src(first), tid, md);
     }
 #pragma unroll 1
     for (u32 it = first; it < L;) {                                // rounds d != i
@@ -315,11 +332,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_main(KsArgs a) {
         for (int r = 0; r < G::E; ++r) v[r] = barrett64(v[r], q, md.qbarr);             // intt1_redu.hpp:36-42
         u32 nit = it + 1;
         if (nit == i) ++nit;
-        W::forward_lazy(v, lds, tid, tb, tb + G::N, q);
-        W::final_reduce(v, q);
-        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N, round_src(nit), tid, md);   // nit <= L
+        W::forward_lazy(v, lds, tid, tb, tb + G::N, q);            // v < 4q
+        mac_keys_i<G>(acc0, acc1, v, a.keys + ((size_t(it) * (L + 1) + i) * 4) * G::N, round_src(nit), tid, md);   // nit <= L
         it = nit;
     }
+    canonical(acc0, q);
+    canonical(acc1, q);
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
