@@ -39,6 +39,12 @@ using namespace hx;
 #ifndef KX_SLOT_MAJOR
 #define KX_SLOT_MAJOR 0
 #endif
+#ifndef KX_NEXT_AUX
+#define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
+#endif
+#ifndef KX_KEY_AUX
+#define KX_KEY_AUX 0    // ... of the key loads
+#endif
 
 // 16 coefficients per thread: the kernels are written for 128 VGPRs = four waves per SIMD, which a 1024-thread workgroup
 // (N = 16384) implies and the smaller ring dimensions (512 ... 64 threads, several workgroups per CU) have to ask for
@@ -135,13 +141,13 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
     const u32 toff = u32(tid) * 8;
     double ka[PF], kb[PF];
 #pragma unroll
-    for (int r = 0; r < PF; ++r) { ka[r] = keys.at(toff, r * G::T * 8); kb[r] = keys.at(toff, (G::N + r * G::T) * 8); }
+    for (int r = 0; r < PF; ++r) { ka[r] = keys.template at<KX_KEY_AUX>(toff, r * G::T * 8); kb[r] = keys.template at<KX_KEY_AUX>(toff, (G::N + r * G::T) * 8); }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
         const double a = ka[r % PF], b = kb[r % PF];
-        if (r + PF < G::E) { ka[r % PF] = keys.at(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.at(toff, (G::N + (r + PF) * G::T) * 8); }
+        if (r + PF < G::E) { ka[r % PF] = keys.template at<KX_KEY_AUX>(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.template at<KX_KEY_AUX>(toff, (G::N + (r + PF) * G::T) * 8); }
         const double x = v[r];
-        v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
+        v[r] = nxt.template at<KX_NEXT_AUX>(toff, G::idxA(r, 0) * 8);
         acc0[r] = hxf::reduce(acc0[r] + hxf::mul_mod(x, a, m), m);
         acc1[r] = hxf::reduce(acc1[r] + hxf::mul_mod(x, b, m), m);
         __builtin_amdgcn_sched_barrier(0);

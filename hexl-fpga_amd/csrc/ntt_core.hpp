@@ -89,9 +89,11 @@ struct RowStream {
     }
     __device__ __forceinline__ RowStream(const V* base, u32 bytes)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(uniform(base), 0, (int)bytes, 0x00020000)) {}
+    // AUX = cache policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); 2 marks a stream nobody re-reads
+    template <int AUX = 0>
     __device__ __forceinline__ V at(u32 thread_byte_offset, u32 row_byte_offset) const {
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)thread_byte_offset, (int)row_byte_offset, 0);
+        const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)thread_byte_offset, (int)row_byte_offset, AUX);
         V d;
         __builtin_memcpy(&d, &x, 8);
         return d;
