@@ -365,6 +365,7 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 // slabs: CPU pack (parallel memcpy) -> H2D on its own stream -> kernels on the context stream -> D2H on a third
 // stream -> CPU unpack, so PCIe traffic in both directions, the kernels and the host copies overlap.
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <thread>
 #include <future>
@@ -455,6 +456,52 @@ static void parallel_for(size_t count, const std::function<void(size_t)>& fn) {
     HostPool::get().wait(HostPool::get().submit(count, fn));
 }
 
+// One persistent helper thread per calling thread (= per device runner): runs the posted jobs in order. The unpack of
+// sub-batch k runs here beside the pack of sub-batch k + 2; a thread spawned per sub-batch (std::async) cost ~40 us each,
+// a third of a single keyswitch's end-to-end time at worksize 1.
+namespace {
+class AsyncLane {
+  public:
+    AsyncLane() : th_([this] { loop(); }) {}
+    ~AsyncLane() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    size_t post(std::function<void()> fn) {                       // returns the job's ticket
+        size_t t;
+        { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(fn)); t = ++posted_; }
+        cv_.notify_all();
+        return t;
+    }
+    void wait(size_t ticket) {
+        std::unique_lock<std::mutex> g(m_);
+        done_cv_.wait(g, [&] { return finished_ >= ticket; });
+    }
+  private:
+    void loop() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [&] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;                               // stop requested and nothing left
+            std::function<void()> fn = std::move(q_.front());
+            q_.pop_front();
+            g.unlock();
+            fn();
+            g.lock();
+            ++finished_;
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::function<void()>> q_;
+    size_t posted_ = 0, finished_ = 0;
+    bool stop_ = false;
+    std::thread th_;                                              // last member: starts after the others exist
+};
+}  // namespace
+
 static int pipe_init(hexl_ctx* c) {
     if (c->s_up) return 0;
     HX_CHECK(hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
@@ -480,7 +527,16 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
                         const std::function<void(size_t, size_t, const char*)>& unpack) {
     int rc = pipe_init(c);
     if (rc) return rc;
-    const size_t S = std::min(batch, sh.sub);
+    // HEXL_HOST_TRACE=1: microseconds since the call started at each step of the staging pipeline (stderr)
+    static const bool trace = [] { const char* e = getenv("HEXL_HOST_TRACE"); return e && atoi(e) == 1; }();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what, size_t k) {
+        if (trace)
+            fprintf(stderr, "[hexl host] %-22s sub-batch %zu  +%8.1f us\n", what, k,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    // at least four sub-batches once there are four items, so that the stages overlap for small windows too
+    const size_t S = std::min(sh.sub, std::max<size_t>(1, (batch + 3) / 4));
     const size_t in_slab = (sh.shared + S * sh.in1 + 255) & ~size_t(255);
     // in-place primitives compute inside the device input slab, but on the HOST side every slab set has its own
     // download area, so that unpacking sub-batch k can overlap packing sub-batch k+2 into the same set
@@ -494,24 +550,44 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     auto d_in = [&](size_t k) { return (char*)c->d_stage + (k & 1) * dset; };
     auto h_out = [&](size_t k) { return h_in(k) + in_slab; };
     auto d_out = [&](size_t k) { return sh.in_place ? d_in(k) + sh.shared : d_in(k) + in_slab; };
-    // unpack(k) runs on a helper thread beside pack(k+2); it must be finished before the download of sub-batch k+2
-    // is enqueued (same host slab) and before unpack(k+1) starts (ordering of accumulating unpacks)
-    std::future<void> unpacking[2];
+    if (nsub == 1) {
+        // one sub-batch: nothing to overlap with -- one stream, one synchronisation, the unpack on the calling thread
+        if (sh.shared) pack_shared(h_in(0));
+        pack(0, batch, h_in(0) + sh.shared);
+        stamp("packed", 0);
+        HX_CHECK(hipMemcpyAsync(d_in(0), h_in(0), sh.shared + batch * sh.in1, hipMemcpyHostToDevice, c->stream));
+        rc = compute(batch, d_in(0), d_out(0));
+        if (rc) return rc;
+        HX_CHECK(hipMemcpyAsync(h_out(0), d_out(0), batch * (sh.in_place ? sh.in1 : sh.out1), hipMemcpyDeviceToHost, c->stream));
+        stamp("enqueued", 0);
+        HX_CHECK(hipStreamSynchronize(c->stream));
+        stamp("download complete", 0);
+        unpack(0, batch, h_out(0));
+        stamp("done", 1);
+        return 0;
+    }
+    // unpack(k) runs on the helper lane beside pack(k+2), strictly in submission order (a keyswitch unpack ACCUMULATES
+    // into the caller's result, and the same result may appear in several sub-batches, benchmark/bench_keyswitch.cpp:
+    // 113-131); it must be finished before the download of sub-batch k+2 is enqueued (same host slab)
+    static thread_local AsyncLane lane;
+    size_t ticket[2] = {0, 0}, last_ticket = 0;
+    struct Drain {                                                // the posted jobs reference this frame: never leave before them
+        AsyncLane& l; size_t& t;
+        ~Drain() { l.wait(t); }
+    } drain{lane, last_ticket};
     for (size_t it = 0; it < nsub + 2; ++it) {
         if (it >= 2) {                                            // drain sub-batch it-2 (frees slab set it&1)
             const size_t k = it - 2, first = k * S, cnt = std::min(S, batch - first);
             HX_CHECK(hipEventSynchronize(c->ev_down[k & 1]));
+            stamp("download complete", k);
             const char* src = h_out(k);
-            // unpacks run strictly one after the other, in submission order: a keyswitch unpack ACCUMULATES into the
-            // caller's result, and the same result may appear in several sub-batches
-            // (benchmark/bench_keyswitch.cpp:113-131). unpack(k) still overlaps pack(k+2) and the copies.
-            if (unpacking[(k + 1) & 1].valid()) unpacking[(k + 1) & 1].get();
-            unpacking[k & 1] = std::async(std::launch::async, [&unpack, first, cnt, src] { unpack(first, cnt, src); });
+            last_ticket = ticket[k & 1] = lane.post([&unpack, &stamp, first, cnt, src, k] { unpack(first, cnt, src); stamp("unpacked", k); });
         }
         if (it < nsub) {
             const size_t first = it * S, cnt = std::min(S, batch - first);
             if (sh.shared) pack_shared(h_in(it));
             pack(first, cnt, h_in(it) + sh.shared);
+            stamp("packed", it);
             HX_CHECK(hipMemcpyAsync(d_in(it), h_in(it), sh.shared + cnt * sh.in1, hipMemcpyHostToDevice, c->s_up));
             HX_CHECK(hipEventRecord(c->ev_up[it & 1], c->s_up));
             HX_CHECK(hipStreamWaitEvent(c->stream, c->ev_up[it & 1], 0));
@@ -519,13 +595,15 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
             if (rc) break;
             HX_CHECK(hipEventRecord(c->ev_comp[it & 1], c->stream));
             HX_CHECK(hipStreamWaitEvent(c->s_down, c->ev_comp[it & 1], 0));
-            if (unpacking[it & 1].valid()) unpacking[it & 1].get();
+            lane.wait(ticket[it & 1]);
             HX_CHECK(hipMemcpyAsync(h_out(it), d_out(it), cnt * (sh.in_place ? sh.in1 : sh.out1), hipMemcpyDeviceToHost,
                                     c->s_down));
             HX_CHECK(hipEventRecord(c->ev_down[it & 1], c->s_down));
+            stamp("enqueued", it);
         }
     }
-    for (auto& f : unpacking) if (f.valid()) f.get();
+    lane.wait(last_ticket);
+    stamp("done", nsub);
     return rc;
 }
 
@@ -697,17 +775,20 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
     // (FPGAObject_KeySwitch::fill_out_data, fpga.cpp:441-475). This keeps the semantics when several objects of a
     // batch alias the same result array, as benchmark/bench_keyswitch.cpp:113-131 does; it also means `result`
     // never crosses PCIe upwards.
+    auto add_limb = [&](u64* res, const u64* out, size_t limb) {  // limb = k * L + i
+        const u64 q = p->moduli[limb % L];
+        const u64* o = out + limb * n;
+        u64* r = res + limb * n;
+        for (size_t j = 0; j < n; ++j) { const u64 v = r[j] + o[j]; r[j] = v - (q & (0 - (u64)(v >= q))); }
+    };
     auto add_into = [&](u64* res, const u64* out) {
-        for (size_t k = 0; k < 2; ++k)
-            for (size_t i = 0; i < L; ++i) {
-                const u64 q = p->moduli[i];
-                const u64* o = out + (k * L + i) * n;
-                u64* r = res + (k * L + i) * n;
-                for (size_t j = 0; j < n; ++j) { const u64 v = r[j] + o[j]; r[j] = v >= q ? v - q : v; }
-            }
+        for (size_t limb = 0; limb < 2 * L; ++limb) add_limb(res, out, limb);
     };
     return run_pipeline(c, batch, sh, [](char*) {},
-        [&](size_t first, size_t cnt, char* h) { parallel_for(cnt, [&](size_t b) { memcpy(h + b * tt, h_t_targets[first + b], tt); }); },
+        [&](size_t first, size_t cnt, char* h) {
+            if (cnt >= 4) parallel_for(cnt, [&](size_t b) { memcpy(h + b * tt, h_t_targets[first + b], tt); });
+            else for (size_t b = 0; b < cnt; ++b) memcpy(h + b * tt, h_t_targets[first + b], tt);
+        },
         [&](size_t cnt, char* d, char* dout) {
             HX_CHECK(hipMemsetAsync(dout, 0, cnt * rs, c->stream));
             return hexl_keyswitch(p, (u64*)dout, (u64*)d, cnt);
@@ -717,7 +798,9 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
             for (size_t a = 0; a < cnt && distinct; ++a)
                 for (size_t b = a + 1; b < cnt; ++b)
                     if (h_results[first + a] == h_results[first + b]) { distinct = false; break; }
-            if (distinct) parallel_for(cnt, [&](size_t b) { add_into(h_results[first + b], (const u64*)(h + b * rs)); });
+            // distinct results: one job per (item, limb) -- a lone keyswitch (worksize 1) still spreads over 2 L threads
+            if (distinct)
+                parallel_for(cnt * 2 * L, [&](size_t x) { add_limb(h_results[first + x / (2 * L)], (const u64*)(h + (x / (2 * L)) * rs), x % (2 * L)); });
             else for (size_t b = 0; b < cnt; ++b) add_into(h_results[first + b], (const u64*)(h + b * rs));
         });
 }
