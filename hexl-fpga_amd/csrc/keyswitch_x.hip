@@ -21,7 +21,8 @@
 //    is reloaded inside the multiply-accumulate, and because vector memory returns in order that reload waits for the
 //    whole key prefetch queue -- 37-45 k cycles per multiply-accumulate instead of 10 k. Hence: straight-line phases
 //    instead of one loop with an up/down branch (128 phi nodes on the accumulators cost ~200 spills), the inverse
-//    transforms in their own kernel (two twiddle tables: 92 working registers), no persistent item loop around k_ksx_main.
+//    transforms in their own kernel (two twiddle tables: 92 working registers), no persistent item loop around k_ksx_main
+//    (KX_MAIN_PERSIST), a key ring of three pairs, not six.
 //  * 16 x 1024 beats 32 x 512 (256 VGPRs, two re-deals instead of three): with two waves per SIMD every exposed load
 //    latency is paid in full; HEXL_KSX_LOGE=5 still selects that geometry (its natural-order arrays then meet the
 //    transforms' "B" register order through an LDS re-deal: a lane owns 16 adjacent words there).
@@ -38,6 +39,9 @@ using namespace hx;
 #endif
 #ifndef KX_SLOT_MAJOR
 #define KX_SLOT_MAJOR 0
+#endif
+#ifndef KX_MAIN_PERSIST
+#define KX_MAIN_PERSIST 0   // k_ksx_main as a persistent item loop per CU
 #endif
 #ifndef KX_NEXT_AUX
 #define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
@@ -128,7 +132,12 @@ __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* 
 // coefficient keeps the compiler from hoisting the whole stream to the top (and spilling what it displaced).
 // (Requesting the next input in one burst behind the last key instead measured the same within noise at four waves per
 // SIMD: 10.4 k against 9.5 k cycles per multiply-accumulate in the timeline tool.)
-constexpr int KX_PF = 6;
+// Ring depth: three pairs measured best (192 k keyswitch/s against 181 k for six and 165 k for eight): the other waves of
+// the SIMD cover the key latency, the registers of a deeper ring are not free -- with three, k_ksx_main spills nothing.
+#ifndef KX_PF_DEPTH
+#define KX_PF_DEPTH 3
+#endif
+constexpr int KX_PF = KX_PF_DEPTH;
 // The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads (RowStream, ntt_core.hpp).
 // acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
 // input, A order (never null)
@@ -382,7 +391,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     const u32 L = a.L;
     // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler
     // hoists out of the item loop costs more registers (34 spilled against 10) than the dispatch gaps cost time
+#if KX_MAIN_PERSIST
+    const XcdWalk wk = xcd_walk(a.nb * L);
+#pragma unroll 1
+    for (u32 item = wk.pos; item < wk.end; item += wk.step)
+#else
     const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));
+#endif
     {
 #if KX_SLOT_MAJOR
     // SLOT-major, XCD-contiguous: an XCD works on one or two limbs at a time, whose keys (2 L n words per limb) then
@@ -503,7 +518,8 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
         hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED>), dim3(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED>), KX_MAIN_PERSIST ? grid_for(a.nb * a.L) : dim3(a.nb * a.L), dim3(G::T),
+                           G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }
