@@ -228,7 +228,18 @@ __device__ __forceinline__ void redeal(u64 (&v)[G::E], u64* lds, int tid, FromId
 
 // compiler-only ordering point for LDS traffic that stays inside one wave (the hardware executes a wave's LDS
 // instructions in order; this keeps the compiler from moving reads above the writes of other lanes)
-__device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }
+#ifndef HX_LDS_ONLY_FENCE
+#define HX_LDS_ONLY_FENCE 0
+#endif
+__device__ __forceinline__ void wave_fence() {
+#if HX_LDS_ONLY_FENCE
+    // orders LDS accesses only: global (twiddle, key) loads may be scheduled across a wave-private re-deal
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
 
 // Re-deal with the minimum of synchronisation. PRIVATE: every coefficient stays inside its wave -> no
 // s_barrier at all, the waves of the workgroup drift apart and cover each other's LDS/memory latency.
