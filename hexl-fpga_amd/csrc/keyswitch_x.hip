@@ -43,6 +43,9 @@ using namespace hx;
 #ifndef KX_MAIN_PERSIST
 #define KX_MAIN_PERSIST 0   // k_ksx_main as a persistent item loop per CU
 #endif
+#ifndef KX_FIRST_DIRECT
+#define KX_FIRST_DIRECT 1   // first multiply-accumulate of k_ksx_main with its keys requested straight into the accumulators
+#endif
 #ifndef KX_NEXT_AUX
 #define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
 #endif
@@ -163,6 +166,31 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
     }
 }
 
+// The FIRST multiply-accumulate of a workgroup (the d == i term): the accumulators are not live yet, so all 2 E key words
+// are requested straight into their registers, right behind the E words of t_i and before anything is waited for -- one
+// memory latency for the whole phase. (Through the three-deep ring this phase took 22 k cycles, twice a later round's:
+// all 16 waves are in it at the same time, nobody has transform work to cover the ring's short reach.)
+template <class G>
+__device__ __forceinline__ void mac_keys_first(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
+                                               const u64* __restrict__ t, const double* __restrict__ k0,
+                                               const double* __restrict__ next, int tid, const Mod m) {
+    static_assert(G::KL <= 2, "direct B-order loads");
+    const RowStream<double> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
+    const u32 toff = u32(tid) * 8, tB = u32(G::idxB(0, tid));
+    u64 raw[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) raw[r] = (t + G::idxB(r, 0))[tB];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) { acc0[r] = keys.at(toff, r * G::T * 8); acc1[r] = keys.at(toff, (G::N + r * G::T) * 8); }
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const double x = hxf::reduce(hxf::to_f64(raw[r]), m);
+        v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
+        acc0[r] = hxf::reduce(hxf::mul_mod(x, acc0[r], m), m);
+        acc1[r] = hxf::reduce(hxf::mul_mod(x, acc1[r], m), m);
+    }
+}
+
 // (x . y) mod p of two natural-order limbs as centred doubles in B register order (fused multiply + relinearize; direct
 // B-order loads, 16-coefficient geometry only). In-range operands: |x|, |y| <= p/2 after centring, |x.y mod p| <= 0.7p.
 template <class G>
@@ -272,6 +300,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 #pragma unroll
         for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = (c0 + G::idxA(r, 0))[u32(tid)]; }
     }
+    // (Walking the limbs in a different order per instance -- the sum is exact, its order free -- does not shorten this
+    // kernel's multiply-accumulate, 12-13 k cycles against 5 k in k_ksx_main: its workgroups start together and stay in
+    // step, so all 16 waves of a CU are in that phase at once and nobody has transform work to cover the key latency.)
 #pragma unroll 1
     for (u32 it = 0; it < L; ++it) {
         int tid = threadIdx.x;                                    // laundered per round (see k_ksf_up)
@@ -414,22 +445,27 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     const u32 first = i == 0 ? 1u : 0u;
     double acc0[G::E], acc1[G::E];
     double v[G::E];                                               // between rounds: the next round's input, A order
-#pragma unroll
-    for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
     {
         // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        KX_STAMP(60);
-        if constexpr (FUSED) {
-            const size_t at = ((size_t(b) * 2 + 1) * L + i) * G::N;
-            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, m);
-        } else {
-            load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
-        }
-        KX_STAMP(61);
         const double* k0 = a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N;
-        mac_keys<G>(acc0, acc1, v, k0, round_src(first), tid, m);
+        KX_STAMP(60);
+        if constexpr (!FUSED && G::KL <= 2 && KX_FIRST_DIRECT) {
+            KX_STAMP(61);
+            mac_keys_first<G>(acc0, acc1, v, a.t_target + (size_t(b) * L + i) * G::N, k0, round_src(first), tid, m);
+        } else {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
+            if constexpr (FUSED) {
+                const size_t at = ((size_t(b) * 2 + 1) * L + i) * G::N;
+                load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, m);
+            } else {
+                load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
+            }
+            KX_STAMP(61);
+            mac_keys<G>(acc0, acc1, v, k0, round_src(first), tid, m);
+        }
     }
     // rounds d != i: acc += NTT(c_d mod q_i) . key[d][i]
 #pragma unroll 1
