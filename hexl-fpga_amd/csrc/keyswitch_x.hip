@@ -571,8 +571,10 @@ u32 hx_ks_x_loge() {                                              // HEXL_KSX_LO
 bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
     static const int pipe = [] { const char* e = getenv("HEXL_KS_PIPE"); return e ? atoi(e) : 2; }();
     if (!p->d_keys_x || p->logn < 10 || p->logn > 14) return false;
-    // one workgroup per (instance, limb) must fill the chip at least twice (a CU holds 16384 / N of them)
-    return pipe == 3 || (pipe == 2 && ((nb * p->L) << p->logn) >= ((2 * (size_t)p->ctx->num_cu) << 14));      // 3: always (tests)
+    // one workgroup per (instance, limb) must nearly fill the chip twice (a CU holds 16384 / N of them): measured at N = 16384,
+    // L = 7 (tools/batch_sweep.py) the slot-major pipeline wins from 64 instances up (141 k against 132 k keyswitch/s), the
+    // (b, d)-major one below 48
+    return pipe == 3 || (pipe == 2 && ((4 * nb * p->L) << p->logn) >= ((7 * (size_t)p->ctx->num_cu) << 14));  // 3: always (tests)
 }
 
 template <int LOGN>

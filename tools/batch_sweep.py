@@ -15,7 +15,7 @@ ctx = hx.Context(0)
 case = KsCase(orc, 16384, 7, 8, seed=1)
 plan = hx.KeySwitchPlan(ctx, 16384, 7, 8, 8, 2, case.moduli, case.modswitch)
 plan.set_keys(case.keys)
-for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 1024):
+for B in (1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 1024):
     d_t, d_r = bench.device_inputs(hx, orc, case, B, dev)
     for _ in range(3):
         plan.keyswitch(d_r, d_t, B)
