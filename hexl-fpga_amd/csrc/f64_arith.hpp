@@ -120,6 +120,21 @@ HX_HD void gs_bfly_lazy(double& X, double& Y, double w, double wp, const Mod m) 
     X = reduce(s, m);
     Y = mul_shoup(d, w, wp, m);
 }
+// Folded multiply-accumulate (LAZY regime; the key multiply-accumulate of the slot-major keyswitch): acc + x*k mod p in
+// EIGHT operations instead of mul_mod + add + reduce = ten -- the accumulator enters the quotient estimate, so the result
+// is reduced in the same step:  acc' = (h - K p) + (acc + l),  K = rint(fl(h/p) + acc/p),  h + l = x*k exactly.
+// Requires |k| <= p/2, |x| <= c p with c as in the forward schedule above (un-reduced transform output), |acc| <= 1.6p.
+//   K differs from (x k + acc)/p by at most 0.5 + (three roundings of a value < 2^52: 0.75) + |l|/p  =>  |acc'| <= 1.6p
+//   exact: acc + l is an integer below 1.6p + 2^49 < 2^52; |h - K p| <= |acc'| + |acc + l| < 3.4p < 2^53; acc' an integer < 2^53.
+// tests/cpp/f64_selftest.cpp replays chains of it against 128-bit integers at extreme operands for every tier.
+HX_HD double mac_fold(double acc, double x, double k, const Mod m) {
+    const double h = x * k;
+    const double l = __builtin_fma(x, k, -h);
+    const double s = acc + l;
+    const double K = __builtin_rint(__builtin_fma(acc, m.pinv, h * m.pinv));
+    return __builtin_fma(-K, m.p, h) + s;
+}
+
 // forward schedule: reduce every element after global stage s (1-based) when s % period == 0 or s is the last stage
 HX_HD constexpr bool lazy_fwd_reduce_after(int s, int logn, int period = 3) { return (s % period == 0) || (s == logn); }
 

@@ -144,7 +144,10 @@ constexpr int KX_PF = KX_PF_DEPTH;
 // The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads (RowStream, ntt_core.hpp).
 // acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
 // input, A order (never null)
-template <class G>
+#ifndef KX_FOLD
+#define KX_FOLD 1     // lazy kernels: folded multiply-accumulate (f64_arith.hpp mac_fold), accumulators <= 1.6p between rounds
+#endif
+template <class G, bool FOLD = false>
 __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
                                          const double* __restrict__ k0, const double* __restrict__ next, int tid,
                                          const Mod m) {
@@ -160,8 +163,13 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
         if (r + PF < G::E) { ka[r % PF] = keys.template at<KX_KEY_AUX>(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.template at<KX_KEY_AUX>(toff, (G::N + (r + PF) * G::T) * 8); }
         const double x = v[r];
         v[r] = nxt.template at<KX_NEXT_AUX>(toff, G::idxA(r, 0) * 8);
-        acc0[r] = hxf::reduce(acc0[r] + hxf::mul_mod(x, a, m), m);
-        acc1[r] = hxf::reduce(acc1[r] + hxf::mul_mod(x, b, m), m);
+        if constexpr (FOLD) {
+            acc0[r] = hxf::mac_fold(acc0[r], x, a, m);
+            acc1[r] = hxf::mac_fold(acc1[r], x, b, m);
+        } else {
+            acc0[r] = hxf::reduce(acc0[r] + hxf::mul_mod(x, a, m), m);
+            acc1[r] = hxf::reduce(acc1[r] + hxf::mul_mod(x, b, m), m);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -318,7 +326,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
         KX_STAMP(4 * it + 2);
-        mac_keys<G>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
+        mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
+    }
+    if constexpr (LAZY != 0 && KX_FOLD) {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
     }
     {
         int tid = threadIdx.x;
@@ -484,8 +496,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* k0 = a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N;
         W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
         KX_STAMP(4 * it + 2);
-        mac_keys<G>(acc0, acc1, v, k0, round_src(nit), tid, m);                      // nit <= L: s'_0 follows the last c_d
+        mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, round_src(nit), tid, m);   // nit <= L: s'_0 follows the last c_d
         it = nit;
+    }
+    if constexpr (LAZY != 0 && KX_FOLD) {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
     }
     // rounds L, L+1 (k = 0, 1)
     {

@@ -98,6 +98,36 @@ static void test_transforms(uint64_t n, uint64_t p) {
 
 // LAZY regime: replay the device schedules (ntt_core_f64.hpp) on the host, tracking the largest magnitude any
 // value reaches (must stay < 2^53) and checking results against the oracle.
+// chains of the folded multiply-accumulate (mac_fold) against exact integers: x up to the un-reduced transform bound of the
+// tier, keys up to p/2, both random and pinned at the extremes with the signs that push the accumulator outwards
+static double g_fold_max = 0;
+static void test_mac_fold(uint64_t p, double c) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    const int64_t P = (int64_t)p;
+    const int64_t xmax = (int64_t)(c * (double)p), kmax = P / 2;
+    for (int chain = 0; chain < 20000; ++chain) {
+        double acc = 0;
+        i128 exact = 0;
+        const int mode = chain % 4;
+        for (int term = 0; term < 16; ++term) {
+            int64_t x, k;
+            if (mode == 0) { x = (int64_t)(rnd() % (2 * (uint64_t)xmax + 1)) - xmax; k = (int64_t)(rnd() % (2 * (uint64_t)kmax + 1)) - kmax; }
+            else {
+                x = xmax - (int64_t)(rnd() % 1024); k = kmax - (int64_t)(rnd() % 1024);
+                const bool up = mode == 1 ? true : mode == 2 ? (acc >= 0) : (term & 1);
+                if (!up) x = -x;
+                if (rnd() & 1) { x = -x; k = -k; }
+            }
+            acc = hxf::mac_fold(acc, (double)x, (double)k, m);
+            exact += (i128)x * k;
+            const double a = acc < 0 ? -acc : acc;
+            if (a / (double)p > g_fold_max) g_fold_max = a / (double)p;
+            CHECK(acc == (double)(int64_t)acc && centred(exact - (int64_t)acc, P) == 0 && a <= 1.6 * (double)p,
+                  "mac_fold p=%lu chain %d term %d acc=%.0f", p, chain, term, acc);
+        }
+    }
+}
+
 static double g_max_abs = 0;
 static inline void track(double x) { double a = x < 0 ? -x : x; if (a > g_max_abs) g_max_abs = a; }
 
@@ -210,6 +240,7 @@ int main() {
             CHECK((double)p <= hxf::LAZY_MAX_MODULUS, "prime %lu not lazy-admissible", p);
             for (uint64_t n : {1024ull, 2048ull, 16384ull}) { test_transforms_lazy(n, p, false); test_transforms_lazy(n, p, true); }
         }
+        for (uint64_t p : primes) if ((double)p <= hxf::LAZY_MAX_MODULUS) test_mac_fold(p, 2.14);
         std::printf("lazy schedules: max |x| seen = 2^%.3f (limit 2^53)\n", log2(g_max_abs));
         CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded");
         // longer reduction periods for smaller moduli (f64_arith.hpp: lazy_period_for): the largest admissible prime
@@ -225,10 +256,12 @@ int main() {
                 CHECK(hxf::lazy_period_for((double)p) >= period, "prime %lu: period %d not admissible", p, period);
                 for (uint64_t n : {1024ull, 16384ull}) { test_transforms_lazy(n, p, false, period); test_transforms_lazy(n, p, true, period); }
             }
+            for (uint64_t p : tp) test_mac_fold(p, tier == 0 ? 4.82 : 9.5);      // two un-reduced tail stages after a reduction
             std::printf("period %2d (p <= 2^%d): max |x| seen = 2^%.3f (limit 2^53)\n", period, tier == 0 ? 50 : 49, log2(g_max_abs));
             CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded for period %d", period);
         }
     }
+    std::printf("folded multiply-accumulate: max |acc| / p seen = %.3f (bound 1.6)\n", g_fold_max);
     std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());
     return failures ? 1 : 0;
 }
