@@ -46,6 +46,10 @@ using namespace hx;
 #ifndef KX_FIRST_DIRECT
 #define KX_FIRST_DIRECT 1   // first multiply-accumulate of k_ksx_main with its keys requested straight into the accumulators
 #endif
+#ifndef KX_PRE
+#define KX_PRE 11     // forward transforms: twiddles of the per-lane passes requested early (ntt_core_f64.hpp WgNttF64 PRE): units = groups of
+                      // the last pass ahead of its re-deal, tens = early stages of the per-lane full pass up front
+#endif
 #ifndef KX_NEXT_AUX
 #define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
 #endif
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;
@@ -429,7 +433,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler

@@ -58,6 +58,53 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
     }
 }
 
+// the same K stages with their 2^K - 1 twiddles already in registers (tw[(1 << u) - 1 + j] = stage u, sub-block j)
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0>
+__device__ __forceinline__ void fwd_stages_f64_tw(double (&v)[E], const double (&tw)[(1 << K) - 1], const Mod m) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const double W = tw[(1 << u) - 1 + j];
+#pragma unroll
+            for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
+                const int a0 = OFF + (j << (K - u)) + c;
+                if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
+                else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
+            }
+        }
+    }
+}
+
+// K per-lane stages with the twiddles of stages 0 .. K-2 (2^(K-1) - 1 of them) requested up front, those of the last stage
+// where the compiler puts them: one exposed wait instead of K - 1 at the price of 2^K - 2 registers. (Requesting stage
+// u + 2 ahead of the butterflies of stage u as well -- two stages' twiddles live -- spilled 24-36 registers in the
+// keyswitch kernels: 179 k against 200 k keyswitch/s.)
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0>
+__device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, const double* __restrict__ w, const Mod m) {
+    double tw[(1 << (K - 1)) - 1];
+#pragma unroll
+    for (int u = 0; u + 1 < K; ++u)
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) tw[(1 << u) - 1 + j] = w[(1u << (S0 - 1 + u)) + (G << u) + j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const double W = u + 1 < K ? tw[(1 << u) - 1 + j] : w[(1u << (S0 - 1 + u)) + (G << u) + j];
+#pragma unroll
+            for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
+                const int a0 = OFF + (j << (K - u)) + c;
+                if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
+                else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
+            }
+        }
+    }
+}
+
 using hxf::InvScale;
 
 template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, int TF = 0>
@@ -112,7 +159,12 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
     __syncthreads();
 }
 
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0>
+// PRE > 0 (register-tight kernels, keyswitch_x.hip): the per-lane twiddles of the first PRE % 10 groups of the LAST (partial)
+// pass are requested before the re-deal that precedes it, those of the other groups right behind it, ahead of all butterflies
+// (194 k -> 200 k keyswitch/s); PRE >= 10: the per-lane full pass requests its early stages' twiddles up front as well
+// (fwd_stages_f64_ahead: -> 202 k). Left alone, a kernel that holds 96 data registers gets every twiddle load of that pass right in
+// front of its first use with an s_waitcnt vmcnt(0) behind it -- eight fully exposed L2 latencies per transform.
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0>
 struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -134,8 +186,30 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF>(v, Gp, w, wp, m);
+            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, m);
+            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
+            if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
+                constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;
+                constexpr int NPRE = (PRE % 10) < G::NG ? (PRE % 10) : G::NG;
+                double tl[G::NG][NT];
+                auto request = [&](int g) {
+                    const u32 Gb = u32(G::grpB(g, tid));
+#pragma unroll
+                    for (int u = 0; u < G::KL; ++u)
+#pragma unroll
+                        for (int j = 0; j < (1 << u); ++j) tl[g][(1 << u) - 1 + j] = w[(1u << (S0L - 1 + u)) + (Gb << u) + j];
+                };
+#pragma unroll
+                for (int g = 0; g < NPRE; ++g) request(g);
+                redeal_pass<G, LO, LOGE, true, LEAD, true>(v, lds, tid);
+#pragma unroll
+                for (int g = NPRE; g < G::NG; ++g) request(g);
+                __builtin_amdgcn_sched_barrier(0);
+                before_last();
+                fwd_last_tw<0, FINAL>(v, tl, m);
+                return;
+            }
             redeal_pass<G, LO, LOGE, true, LEAD, (PASS + 1 == G::P - 1)>(v, lds, tid);
             if constexpr (PASS == 0) after_cross();
             fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m, NoHook(), before_last);
@@ -152,6 +226,13 @@ struct WgNttF64 {
             // LOGN = 0 tells the stage loop that no stage is the last one
             fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
+        }
+    }
+    template <int GRP, bool FINAL = true>
+    __device__ static __forceinline__ void fwd_last_tw(double (&v)[E], const double (&tl)[G::NG][(1 << G::KL) - 1], const Mod m) {
+        if constexpr (GRP < G::NG) {
+            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY>(v, tl[GRP], m);
+            fwd_last_tw<GRP + 1, FINAL>(v, tl, m);
         }
     }
     template <bool FRESH = false, bool FINAL = true, class Hook = NoHook, class Hook2 = NoHook>
