@@ -50,6 +50,9 @@ using namespace hx;
 #define KX_PRE 11     // forward transforms: twiddles of the per-lane passes requested early (ntt_core_f64.hpp WgNttF64 PRE): units = groups of
                       // the last pass ahead of its re-deal, tens = early stages of the per-lane full pass up front
 #endif
+#ifndef KX_IPRE
+#define KX_IPRE 1     // k_ksx_intt: the per-lane twiddle pairs of a pass of the inverse transform requested before its butterflies
+#endif
 #ifndef KX_NEXT_AUX
 #define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
 #endif
@@ -276,10 +279,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
             const u32 nitem = item + wk.step < wk.end ? item + wk.step : item;       // (last round: a harmless re-read)
             const u64* pn = src_of(nitem);
             const u32 tB = u32(G::idxB(0, tid));
-            W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, [&] {
+            auto request_next = [&] {
 #pragma unroll
                 for (int r = 0; r < G::E; ++r) raw[r] = (pn + G::idxB(r, 0))[tB];
-            });
+            };
+            W::template inverse<false, decltype(request_next), (KX_IPRE != 0)>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, request_next);
         } else {
             load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m);
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);

@@ -149,6 +149,47 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
     }
 }
 
+// The same K inverse stages with all their 2^K - 1 twiddle pairs requested before the first butterfly (IPRE, kernels with
+// registers to spare: k_ksx_intt). Left alone the compiler requests each pair right in front of its use and waits for it:
+// up to 15 exposed latencies per per-lane pass.
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0>
+__device__ __forceinline__ void inv_stages_f64_pre(double (&v)[E], u32 G, const double* __restrict__ iw,
+                                                   const double* __restrict__ iwp, const Mod m, const InvScale sc) {
+    constexpr u32 N = 1u << LOGN;
+    constexpr int NT = (1 << K) - 1;
+    double tw[NT], twp[NT];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool fused = LAST && (u == K - 1);
+        const u32 base = N - (N >> (LO + u)) + 1 + (G << (K - 1 - u));
+#pragma unroll
+        for (int j = 0; j < (1 << (K - 1 - u)); ++j)
+            if (!fused) { tw[(1 << K) - (1 << (K - u)) + j] = iw[base + j]; twp[(1 << K) - (1 << (K - u)) + j] = iwp[base + j]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool fused = LAST && (u == K - 1);
+#pragma unroll
+        for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
+            const double W = fused ? 0.0 : tw[(1 << K) - (1 << (K - u)) + j], Wp = fused ? 0.0 : twp[(1 << K) - (1 << (K - u)) + j];
+#pragma unroll
+            for (int c = 0; c < (1 << u); ++c) {
+                const int a0 = OFF + (j << (u + 1)) + c;
+                const int a1 = a0 + (1 << u);
+                if (!fused) {
+                    if (LAZY) hxf::gs_bfly_lazy(v[a0], v[a1], W, Wp, m);
+                    else      hxf::gs_bfly(v[a0], v[a1], W, Wp, m);
+                } else {
+                    const double s = v[a0] + v[a1], d = v[a0] - v[a1];
+                    v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
+                    v[a1] = hxf::reduce(hxf::mul_shoup(d, sc.nw, sc.nw_p, m), m);
+                }
+            }
+        }
+    }
+}
+
 template <class G, class FromIdx, class ToIdx>
 __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int tid, FromIdx from, ToIdx to) {
 #pragma unroll
@@ -265,13 +306,14 @@ struct WgNttF64 {
     }
 
     // inverse: B layout in, A layout out, centred, scaled by n^-1
-    template <int GRP>
+    template <int GRP, bool IPRE = false>
     __device__ static __forceinline__ void inv_first(double (&v)[E], int tid, const double* iw, const double* iwp,
                                                      const Mod m, const InvScale sc) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
-            inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, false, TF>(v, Gbits, iw, iwp, m, sc);
-            inv_first<GRP + 1>(v, tid, iw, iwp, m, sc);
+            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY>(v, Gbits, iw, iwp, m, sc);
+            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, false, TF>(v, Gbits, iw, iwp, m, sc);
+            inv_first<GRP + 1, IPRE>(v, tid, iw, iwp, m, sc);
         }
     }
     // `before_uniform` runs once, right after the re-deal that precedes the first pass whose twiddles are wave-uniform
@@ -279,7 +321,7 @@ struct WgNttF64 {
     // (a persistent kernel's next input) delays nothing -- vector memory returns in order.
     template <int PASS>
     static constexpr bool inv_pass_uniform = (PASS == G::P - 2) || (G::KL + PASS * LOGE >= 6);
-    template <int PASS, bool FRESH = false, class Hook = NoHook>
+    template <int PASS, bool FRESH = false, class Hook = NoHook, bool IPRE = false>
     __device__ static __forceinline__ void inv_pass(double (&v)[E], double* lds, int tid, const double* iw,
                                                     const double* iwp, const Mod m, const InvScale sc,
                                                     Hook before_uniform = Hook()) {
@@ -289,16 +331,17 @@ struct WgNttF64 {
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             if constexpr (inv_pass_uniform<PASS> && (PASS == 0 || !inv_pass_uniform<(PASS > 0 ? PASS - 1 : 0)>)) before_uniform();
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF>(v, Gp, iw, iwp, m, sc);
-            inv_pass<PASS + 1, FRESH>(v, lds, tid, iw, iwp, m, sc, before_uniform);
+            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, LOGN, false, LAZY>(v, Gp, iw, iwp, m, sc);
+            else inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF>(v, Gp, iw, iwp, m, sc);
+            inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform);
         }
     }
-    template <bool FRESH = false, class Hook = NoHook>
+    template <bool FRESH = false, class Hook = NoHook, bool IPRE = false>
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
                                                    const double* iwp, const Mod m, const InvScale sc,
                                                    Hook before_uniform = Hook()) {
-        inv_first<0>(v, tid, iw, iwp, m, sc);
-        inv_pass<0, FRESH>(v, lds, tid, iw, iwp, m, sc, before_uniform);
+        inv_first<0, IPRE>(v, tid, iw, iwp, m, sc);
+        inv_pass<0, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform);
     }
 };
 
