@@ -164,11 +164,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # HEXL_BENCH_ONE_GPU=1 (pre-flight test of the N > 1 path on a one-GPU box, tests/test_gpu_bench_ranks.py): every rank
+    # uses GPU 0 and the timing barrier / max-reduce go through gloo (RCCL refuses two ranks on one device)
+    one_gpu = os.environ.get("HEXL_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:
@@ -201,7 +209,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)                              # HIP events on the launch stream
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
