@@ -1,10 +1,11 @@
-// keyswitch_x.hip -- K4 on the FP64 pipe, SLOT-MAJOR pipeline for large batches (N = 16384): the key
+// keyswitch_x.hip -- K4 on the FP64 pipe, SLOT-MAJOR pipeline for large batches (N = 1024 .. 16384): the key
 // multiply-accumulate (device/keyswitch/dyadmult.hpp:85-166) runs in the registers of the
 // workgroup that produced the transforms, as the reference's pipes do -- `u` (15 MB per keyswitch in the (b, d)-major
 // pipeline of keyswitch_f64.hip) and `prod` never exist in memory.
 //
-// One workgroup = 1024 threads x 16 coefficients (Geom<14,4>, 128 VGPRs per thread): 32 registers hold the polynomial
-// in flight, 64 the two accumulators (prod[k][slot], k = 0, 1), the rest is working space. Three kernels per chunk:
+// One workgroup = N/16 threads x 16 coefficients (Geom<LOGN,4>: 1024 threads at N = 16384; 128 VGPRs per thread): 32
+// registers hold the polynomial in flight, 64 the two accumulators (prod[k][slot], k = 0, 1), the rest is working space.
+// Three kernels per chunk:
 //
 //   k_ksx_intt    (b, d)    c_d = INTT_{q_d}(t_target[d])  -> scratch (canonical doubles, natural order)       (step 1)
 //   k_ksx_special (b)       acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k]                       (steps 2-3)
@@ -12,7 +13,7 @@
 //   k_ksx_main    (b, i<L)  acc_k = sum_d NTT_{q_i}(c_d mod q_i) . key[d][i][k]   (d == i: t_target[i] itself)
 //                           k = 0, 1:  w = NTT_{q_i}((s'_k + fix_i) mod q_i);  result[k][i] += (acc_k - w) . msf_i  (steps 5-7)
 //
-// HBM-side traffic per keyswitch (PMC, profiles/): 17.5 MB against 25.6 MB for the (b, d)-major pipeline and 4.6 MB
+// HBM-side traffic per keyswitch (PMC, profiles/): 14.5 MB against 25.6 MB for the (b, d)-major pipeline and 4.6 MB
 // algorithmic. Arithmetic and bounds are those of f64_arith.hpp; results are bit-identical to the (b, d)-major
 // pipeline and the integer kernels.
 //
@@ -27,6 +28,8 @@
 //    latency is paid in full; HEXL_KSX_LOGE=5 still selects that geometry (its natural-order arrays then meet the
 //    transforms' "B" register order through an LDS re-deal: a lane owns 16 adjacent words there).
 //  * The NEXT round's input is requested inside the multiply-accumulate, into the registers the products free.
+//  * Per-lane twiddles are requested by hand ahead of their butterflies (KX_PRE, KX_IPRE): with 96 data registers the
+//    compiler otherwise puts each load in front of its first use and waits for it on the spot.
 #include <stdlib.h>
 
 #include "hexl_internal.hpp"
