@@ -2,15 +2,23 @@
 """bench.py -- headline benchmark of the hexl-fpga hot path on MI355X.
 
 Metric (BASELINE.json): keyswitches/sec at N=16384, decomp_modulus_size=7 (key_modulus_size=8,
-52-bit primes), data resident in HBM; one "step" = one hexl_keyswitch() pass over the rank's batch of
-synthetic ciphertexts. Ranks (one per GPU) each own an independent shard of the batch -- no collective on
-the data path -- so `scaling` is weak and `value` = all ranks' keyswitches / max-over-ranks time.
+52-bit primes), data resident in HBM; one "step" = one hexl_keyswitch() pass over the rank's shard of the
+step's batch of synthetic ciphertexts. Ranks (one per GPU) each own an independent contiguous shard
+(hexl_fpga_amd.sharding.shard_range) -- no collective on the data path; `value` = all ranks'
+keyswitches / max-over-ranks wall time.
 
-    python bench.py [--gpus N --steps K --warmup W --batch B]
+    python bench.py [--gpus N --steps K --warmup W] [--total-batch T | --batch B]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline`, `cpu_baseline` and `extra`
-(fwd/inv NTT rates, per-stage kernel times, the reference-representable L=6/K=7 shape).
+Default = BASELINE config 5 as stated: ONE batch of 8192 ciphertexts per step split over the ranks (8192 on one GPU,
+1024 per GPU on eight) -- `scaling: "strong"`. `--batch B` instead gives every rank B ciphertexts per step
+(`scaling: "weak"`). `--barrier-per-step` synchronises all ranks after every step (pre-flight of the regime where a
+step is 5 ms: tests/test_gpu_bench_ranks.py).
+
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (its `traffic` and `alu` inputs are PMC passes
+of tools/pmc_workload run INSIDE this benchmark at N = 1; --no-pmc falls back to profiles/*_latest.json), `cpu_baseline`
+and `extra` (fwd/inv NTT rates over ALL ranks -- BASELINE's second metric --, per-stage kernel times, the
+reference-representable L=6/K=7 shape).
 """
 import argparse
 import json
@@ -51,7 +59,10 @@ def device_inputs(hx, orc_mod, case, batch, dev, distinct=None):
     return t.reshape(batch, -1), r.reshape(batch, -1)
 
 
-def time_ntt(hx, ctx, orc_mod, dev, batch, iters):
+def time_ntt(hx, ctx, orc_mod, dev, batch, iters, barrier=None, max_over_ranks=None, world=1):
+    """BASELINE config 2 shape (fwd / inv NTT, N = 16384, one 52-bit prime, `batch` polynomials per launch) on EVERY rank:
+    per-rank device time from HIP events, and -- BASELINE's second metric -- the whole-job rate = world x batch x iters /
+    the slowest rank's wall time between two barriers"""
     import torch
     q = orc_mod.primes(1, 51, N)[0]
     tb = orc_mod.HexlTables(N, q)
@@ -67,15 +78,25 @@ def time_ntt(hx, ctx, orc_mod, dev, batch, iters):
                 ctx.ntt_inv(x, tabs[2], tabs[3], q, tb.inv_n, tb.inv_n_w, N)
         run()
         torch.cuda.synchronize()
+        if barrier:
+            barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
         e0.record()
         for _ in range(iters):
             run()
         e1.record()
-        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        else:
+            torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if max_over_ranks:
+            wall = max_over_ranks(wall)
         ms = e0.elapsed_time(e1) / iters
         out[name] = {"ms_per_launch": ms, "ntt_per_s": batch / (ms * 1e-3),
-                     "alg_GBps": batch * 2 * N * 8 / (ms * 1e-3) / 1e9}
+                     "alg_GBps": batch * 2 * N * 8 / (ms * 1e-3) / 1e9,
+                     "ntt_per_s_all_ranks": world * batch * iters / wall, "n_gpus": world}
     return out
 
 
@@ -143,21 +164,79 @@ def ctx_cus(ctx):
     return int(m.group(1)) if m else 256
 
 
+PMC_BATCH = 256   # one scratch chunk: every dispatch of the passes below is one whole chunk of 256 keyswitches
+
+
+def pmc_inrun(L, cus, timeout_s=90):
+    """The roofline block's counter inputs measured INSIDE this benchmark run: rocprofv3 PMC passes (one counter group per
+    run, --kernel-trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE and WRITE_SIZE in their own passes) of the native
+    workload tools/pmc_workload (2 launches of a 256-keyswitch chunk, same library, same kernels), plus two passes with every
+    key row aliased onto row 0 (HEXL_KSX_KEY_ALIAS=1): the difference is the key stream's share of the L2-miss-side bytes,
+    which the 256 MiB Infinity Cache serves (the key set is 14.7 MB), so what is left estimates the DRAM side.
+    Returns (derived dict, None) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = ROOT / "tools" / "pmc_workload"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not exe.exists():
+        return None, "tools/pmc_workload not built"
+    if not Path(rocprof).exists():
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCP_TOOL", "ROCPROF")) for k in os.environ):
+        return None, "this process itself runs under a profiler (no nested rocprofv3)"
+    sys.path.insert(0, str(ROOT / "tools"))
+    import pmc_summary
+    env = dict(os.environ, TMPDIR="/tmp", HEXL_KS_ONE_LANE="1")
+    groups = ["SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU", "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY",
+              "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"]
+
+    def passes(root, groups, extra_env):
+        for i, g in enumerate(groups):
+            cmd = [rocprof, "--kernel-trace", "--pmc", *g.split(), "-d", f"{root}/p{i + 1}", "--", str(exe), str(PMC_BATCH), str(L), "2"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(env, **extra_env), timeout=timeout_s, capture_output=True, text=True)
+            if r.returncode:
+                raise RuntimeError(f"rocprofv3 pass '{g}' exited {r.returncode}: {r.stderr[-300:]}")
+        vals, dur = pmc_summary.collect(root)
+        return pmc_summary.derive(vals, dur, PMC_BATCH, L, simds=4 * cus)
+    try:
+        with tempfile.TemporaryDirectory(prefix="hexl_pmc_", dir="/tmp") as tmp:
+            d = passes(tmp + "/a", groups, {})
+            if d["traffic_bytes_per_keyswitch"] is None or d["valu_wave_instructions_per_keyswitch"] is None:
+                return None, "PMC passes returned no counters for the keyswitch kernels"
+            try:
+                al = passes(tmp + "/b", ["FETCH_SIZE", "WRITE_SIZE"], {"HEXL_KSX_KEY_ALIAS": "1"})
+                d["traffic_bytes_per_keyswitch_keys_aliased"] = al["traffic_bytes_per_keyswitch"]
+            except Exception as e:                                  # the estimate is optional
+                d["traffic_bytes_per_keyswitch_keys_aliased"] = None
+                d["keys_aliased_error"] = str(e)[:200]
+            return d, None
+    except Exception as e:
+        return None, f"{type(e).__name__}: {str(e)[:300]}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="keyswitches per GPU per step (44 GB of ciphertexts at the default)")
+    ap.add_argument("--total-batch", type=int, default=None,
+                    help="keyswitches per step over ALL GPUs, split into contiguous shards (strong scaling; default 8192 = BASELINE config 5; "
+                         "44 GB of ciphertexts on one GPU)")
+    ap.add_argument("--batch", type=int, default=None, help="keyswitches per GPU per step instead (weak scaling)")
+    ap.add_argument("--barrier-per-step", action="store_true", help="all ranks synchronise after every step (pre-flight of short steps)")
     ap.add_argument("--decomp", type=int, default=7, help="decomp_modulus_size L (key_modulus_size = L+1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic / roofline.alu from profiles/*_latest.json instead of in-run PMC passes")
     a = ap.parse_args()
+    assert not (a.batch and a.total_batch), "--batch (per GPU, weak) and --total-batch (all GPUs, strong) exclude each other"
 
     import torch
     import torch.distributed as dist
     import hexl_fpga_amd as hx
     import orc as orc_mod
+    from hexl_fpga_amd.sharding import max_over_ranks, shard_range
     from ks_util import KsCase
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,100 +258,143 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
+        torch.cuda.synchronize()                                  # this rank's work is done ...
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier()                                        # ... and so is everybody else's
+            torch.cuda.synchronize()
+
+    def slowest(seconds):
+        return max_over_ranks(seconds, "cpu" if one_gpu else dev)
+
+    # the step's batch and this rank's shard of it (independent ciphertexts: no data-path collective)
+    if a.batch:
+        scaling, total = "weak", a.batch * world
+        first, last = rank * a.batch, (rank + 1) * a.batch
+    else:
+        scaling, total = "strong", a.total_batch or 8192
+        first, last = shard_range(total, world, rank)
+    mine = last - first
+    assert mine > 0, "more ranks than ciphertexts"
 
     ctx = hx.Context(local)
     L, K = a.decomp, a.decomp + 1
-    case = KsCase(orc_mod, N, L, K, seed=1 + rank)          # every rank: its own shard of ciphertexts
+    case = KsCase(orc_mod, N, L, K, seed=1)                   # one key set for the job, replicated on every GPU
     plan = hx.KeySwitchPlan(ctx, N, L, K, L + 1, 2, case.moduli, case.modswitch)
     plan.set_keys(case.keys)
-    d_t, d_r = device_inputs(hx, orc_mod, case, a.batch, dev)
+    case.seed = 1 + rank                                      # every rank: its own ciphertexts
+    d_t, d_r = device_inputs(hx, orc_mod, case, mine, dev)
 
-    # in-run check of the measured path: instance 0 of the first full-batch launch against the oracle
-    t0_host, r0_host = hx.to_u64(d_t[0]).copy(), hx.to_u64(d_r[0]).copy()
-    plan.keyswitch(d_r, d_t, a.batch)
+    # in-run check of the measured path: instances on both sides of a scratch-chunk boundary and the last one of the first
+    # full-batch launch against the oracle
+    probe = sorted({b for b in (0, 255, 256, mine - 1) if 0 <= b < mine})
+    before = {b: (hx.to_u64(d_t[b]).copy(), hx.to_u64(d_r[b]).copy()) for b in probe}
+    plan.keyswitch(d_r, d_t, mine)
     ctx.sync()
-    verified = bool(np.array_equal(hx.to_u64(d_r[0]), case.expected(orc_mod, t0_host, r0_host)))
+    verified = all(bool(np.array_equal(hx.to_u64(d_r[b]), case.expected(orc_mod, *before[b]))) for b in probe)
     assert verified, "keyswitch output differs from the oracle"
     for _ in range(a.warmup):
-        plan.keyswitch(d_r, d_t, a.batch)
+        plan.keyswitch(d_r, d_t, mine)
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(a.steps):
-        plan.keyswitch(d_r, d_t, a.batch)
+        plan.keyswitch(d_r, d_t, mine)
+        if a.barrier_per_step:
+            barrier()
     e1.record()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = slowest(time.perf_counter() - t0)
     dev_ms = e0.elapsed_time(e1)                              # HIP events on the launch stream
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cpu" if one_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
-    total_ks = a.batch * a.steps * world
-    value = total_ks / elapsed
+    value = total * a.steps / elapsed
     out = {
         "metric": "keyswitches/sec at N=16384, decomp=7", "value": value, "unit": "keyswitches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "verified_vs_oracle": verified,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "verified_vs_oracle": verified, "verified_instances": probe,
         "config": {"workload": f"keyswitch N={N} decomp_modulus_size={L} key_modulus_size={K} 52-bit primes "
-                               f"(GeneratePrimes(K,51,N)), kcc=2, batch {a.batch}/GPU resident in HBM",
+                               f"(GeneratePrimes(K,51,N)), kcc=2, batch {total} per step"
+                               + (f" = {a.batch}/GPU" if scaling == "weak" else f" split over {world} GPU(s) ({mine} on rank 0)")
+                               + ", resident in HBM",
+                   "global_batch": total, "batch_per_gpu": mine, "barrier_per_step": bool(a.barrier_per_step),
                    "parallelism": f"{world} independent shard(s), no collective"},
     }
+    # BASELINE's second metric, fwd-NTT/sec at N=16384 at 1/2/4/8 GPUs: config 2's shape on every rank, whole-job rate
+    ntt = None if a.no_extra else time_ntt(hx, ctx, orc_mod, dev, 1024, 10, barrier, slowest, world)
     if rank == 0:
         alg = ks_alg_bytes(N, L)
-        ach = alg * a.batch * a.steps / (dev_ms * 1e-3) / 1e9          # this rank, device-timed
-        stage = plan.time_stages(d_r, d_t, min(a.batch, 256), 3)
-        us_per_ks = dev_ms * 1e3 / (a.batch * a.steps)
-        # Both bounds, recomputable from profiles/ alone (tools/pmc_summary.py writes the two JSON files from the PMC
-        # passes of tools/pmc_quick.sh): HBM-side bytes = sum over the pipeline's kernels of 2*FETCH_SIZE + WRITE_SIZE;
-        # FP64 issue time = VALU instructions per keyswitch (SQ_INSTS_VALU) x 4 cycles (one wave64 FP64 instruction on
-        # a SIMD, MI355X_MICROARCH.md: 78.6 TFLOP/s vector FP64) / (4 SIMDs x CUs) / shader clock under this load
-        traffic, traffic_src, alu = None, None, None
-        tj = ROOT / "profiles" / "traffic_latest.json"
-        if tj.exists():
-            t = json.loads(tj.read_text())
-            if t.get("L") == L:
-                traffic = t["keyswitch_traffic_bytes_per_unit"] * a.batch
-                traffic_src = "profiles/traffic_latest.json (PMC passes of tools/pmc_quick.sh, per keyswitch x batch)"
-        aj = ROOT / "profiles" / "alu_latest.json"
-        if aj.exists():
-            t = json.loads(aj.read_text())
-            if t.get("L") == L:
-                clk = t.get("shader_clock_ghz", 2.0)
-                issue_us = t["valu_wave_instructions_per_keyswitch"] * 4.0 / (4 * ctx_cus(ctx)) / (clk * 1e3)
-                alu = {"bound": "valu_fp64", "valu_wave_instructions_per_keyswitch": t["valu_wave_instructions_per_keyswitch"],
-                       "cycles_per_wave_instruction": 4, "simds": 4 * ctx_cus(ctx), "shader_clock_ghz": clk,
-                       "issue_us_per_keyswitch": issue_us, "measured_us_per_keyswitch": us_per_ks,
-                       "achieved_frac": issue_us / us_per_ks, "source": "profiles/alu_latest.json (SQ_INSTS_VALU per kernel)"}
+        ach = alg * mine * a.steps / (dev_ms * 1e-3) / 1e9            # this rank, device-timed
+        stage = plan.time_stages(d_r, d_t, min(mine, 256), 3)
+        us_per_ks = dev_ms * 1e3 / (mine * a.steps)
+        cus = ctx_cus(ctx)
+        # Both bounds. L2-miss-side bytes = sum over the pipeline's kernels of 2*FETCH_SIZE + WRITE_SIZE; FP64 issue time =
+        # VALU instructions per keyswitch (SQ_INSTS_VALU) x 4 cycles (one wave64 FP64 instruction on a SIMD,
+        # MI355X_MICROARCH.md: 78.6 TFLOP/s vector FP64) / (4 SIMDs x CUs) / shader clock under this load. Measured by PMC passes
+        # run from inside this benchmark (pmc_inrun); profiles/*_latest.json (the round's committed passes) only as fallback.
+        traffic, traffic_src, alu, pmc, why = None, None, None, None, "--no-pmc"
+        if not a.no_pmc and world == 1:
+            ctx.sync()
+            pmc, why = pmc_inrun(L, cus)
+        traffic_extra = {}
+        if pmc:
+            traffic = pmc["traffic_bytes_per_keyswitch"] * mine
+            traffic_src = f"PMC passes run inside this benchmark (rocprofv3 --kernel-trace --pmc, tools/pmc_workload, chunk of {PMC_BATCH}), per keyswitch x batch"
+            vw, clk = pmc["valu_wave_instructions_per_keyswitch"], pmc["shader_clock_ghz"] or 2.0
+            alu_src = "in-run PMC passes (SQ_INSTS_VALU, GRBM_GUI_ACTIVE per kernel)"
+            al = pmc.get("traffic_bytes_per_keyswitch_keys_aliased")
+            if al:
+                # written once (c, s'), compulsory, or re-read from another XCD: everything except the key rows, which come out of the
+                # Infinity Cache (14.7 MB key set against 256 MiB)
+                traffic_extra = {"key_stream_bytes_per_keyswitch": pmc["traffic_bytes_per_keyswitch"] - al,
+                                 "dram_side_estimate_bytes_per_keyswitch": al,
+                                 "dram_side_estimate_note": "L2-miss-side bytes of the same passes with every key row aliased onto row 0 "
+                                                            "(HEXL_KSX_KEY_ALIAS=1): the key stream (L2 misses served by the Infinity Cache) removed"}
+            per_kernel = {k: {kk: e.get(kk) for kk in ("avg_us_under_pmc", "fp64_issue_frac", "wave_time_split", "read_bytes", "write_bytes")}
+                          for k, e in pmc["kernels"].items()}
+        else:
+            tj, aj = ROOT / "profiles" / "traffic_latest.json", ROOT / "profiles" / "alu_latest.json"
+            vw = clk = None
+            per_kernel = None
+            if tj.exists() and json.loads(tj.read_text()).get("L") == L:
+                traffic = json.loads(tj.read_text())["keyswitch_traffic_bytes_per_unit"] * mine
+                traffic_src = f"profiles/traffic_latest.json (committed PMC passes, not this run: {why})"
+            if aj.exists() and json.loads(aj.read_text()).get("L") == L:
+                t = json.loads(aj.read_text())
+                vw, clk = t["valu_wave_instructions_per_keyswitch"], t.get("shader_clock_ghz", 2.0)
+                alu_src = f"profiles/alu_latest.json (committed PMC passes, not this run: {why})"
+        if vw:
+            issue_us = vw * 4.0 / (4 * cus) / (clk * 1e3)
+            alu = {"bound": "valu_fp64", "valu_wave_instructions_per_keyswitch": vw,
+                   "cycles_per_wave_instruction": 4, "simds": 4 * cus, "shader_clock_ghz": clk,
+                   "issue_us_per_keyswitch": issue_us, "measured_us_per_keyswitch": us_per_ks,
+                   "achieved_frac": issue_us / us_per_ks, "source": alu_src, "per_kernel": per_kernel}
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "alg_bytes_per_launch": alg * a.batch,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_kind": "L2-miss side (2 x FETCH_SIZE + WRITE_SIZE at the L2's fabric port): includes what the Infinity Cache serves",
+                           "traffic_source": traffic_src, **traffic_extra,
+                           "alg_bytes_per_launch": alg * mine,
                            "kernel": "keyswitch pipeline (k_ksx_intt + k_ksx_special + k_ksx_main; chunks of 256 keyswitches)",
                            "alg_bytes_per_keyswitch": alg, "device_ms_per_step": dev_ms / a.steps,
                            # per chunk of 256, from hipEvents on the launch stream (compare avg_us in profiles/*kernel_trace*)
                            "dominant_kernel": {"name": "k_ksx_main (steps 2-3 of the L decomposition limbs, steps 5-7)",
                                                "ms_per_chunk": stage[3], "share_of_pipeline": stage[3] / stage[0],
-                                               "chunk": min(a.batch, 256)},
+                                               "chunk": min(mine, 256)},
                            # the binding bound: 72 N-point transforms of exact 52-bit arithmetic per 4.6 MB
                            "alu": alu}
-        extra = {"stage_ms_at_batch_%d" % min(a.batch, 256): {"total": stage[0], "step_1_inverse_transforms": stage[1],
+        extra = {"stage_ms_at_batch_%d" % min(mine, 256): {"total": stage[0], "step_1_inverse_transforms": stage[1],
                                                              "steps_2_4_special_limb": stage[2],
                                                              "steps_2_3_5_7_decomposition_limbs": stage[3]},
                  "device": ctx.describe()}
-        if not a.no_extra:
-            extra["ntt_N16384_batch1024"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 10)
+        if ntt:
+            extra["ntt_N16384_batch1024"] = ntt
+        if not a.no_extra and world == 1:
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
             def other_shape(Lx, Kx, moduli=None, n=N):
                 cs = KsCase(orc_mod, n, Lx, Kx, seed=99, moduli=moduli)
                 pl = hx.KeySwitchPlan(ctx, n, Lx, Kx, Kx, 2, cs.moduli, cs.modswitch)
                 pl.set_keys(cs.keys)
-                nbx = min(a.batch, 2048) * (N // n)
+                nbx = min(mine, 2048) * (N // n)
                 tx, rx = device_inputs(hx, orc_mod, cs, nbx, dev)
                 pl.keyswitch(rx, tx, nbx)
                 torch.cuda.synchronize()
@@ -288,7 +410,7 @@ def main():
                         "alg_GBps": ks_alg_bytes(n, Lx) * nbx / (ms * 1e-3) / 1e9}
             # ciphertext multiply + relinearize: DyadicMultiply then KeySwitch as two primitives vs the fused pass
             def mulrelin():
-                nbx = min(a.batch, 2048)
+                nbx = min(mine, 2048)
                 g = torch.Generator(device=dev)
                 g.manual_seed(5)
                 xa = torch.empty((nbx, 2, L, N), dtype=torch.int64, device=dev)

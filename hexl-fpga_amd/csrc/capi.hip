@@ -247,7 +247,8 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
     }
     HX_CHECK(hipMalloc((void**)&p->d_mods, K * sizeof(KsModulus)));
     HX_CHECK(hipMalloc((void**)&p->d_tables, tables.size() * sizeof(u64)));
-    HX_CHECK(hipMalloc((void**)&p->d_keys, size_t(L) * (L + 1) * 4 * n * sizeof(u64)));     // key words + Shoup factors
+    // integer-kernel keys (key words + Shoup factors): only plans that run the integer kernels hold them
+    if (!f64_ok) HX_CHECK(hipMalloc((void**)&p->d_keys, size_t(L) * (L + 1) * 4 * n * sizeof(u64)));
     HX_CHECK(hipMemcpy(p->d_mods, mods.data(), K * sizeof(KsModulus), hipMemcpyHostToDevice));
     HX_CHECK(hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(u64), hipMemcpyHostToDevice));
     *out = p;
@@ -271,6 +272,8 @@ extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
     if (p->d_tables_f64) (void)hipFree(p->d_tables_f64);
     if (p->d_keys_f64) (void)hipFree(p->d_keys_f64);
     if (p->d_keys_x) (void)hipFree(p->d_keys_x);
+    if (p->d_flag) (void)hipFree(p->d_flag);
+    if (p->h_flag) (void)hipHostFree(p->h_flag);
     delete p;
     return 0;
 }
@@ -282,13 +285,16 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     if (!p || !h_keys) return HEXL_E_BADARG;
     HX_CHECK(hipSetDevice(p->ctx->device));
     const u64 n = p->n, L = p->L, K = p->K;
-    const std::vector<u32> perm = ks_perm(p->logn, p->int_loge);
-    // integer kernels: [d][slot][k][0] = key mod q, [..][1] = floor(that * 2^64 / q) (only computed when they can run)
-    std::vector<u64> dev(size_t(L) * (L + 1) * 4 * n);
+    // integer kernels: [d][slot][k][0] = key mod q, [..][1] = floor(that * 2^64 / q); FP64 plans never run them and hold
+    // no integer copy (22 MB of device memory and a host pass per key set for nothing)
+    std::vector<u64> dev;
+    std::vector<u32> perm;
+    const size_t words = size_t(L) * (L + 1) * 2 * n;
+    if (!p->use_f64) { dev.resize(2 * words); perm = ks_perm(p->logn, p->int_loge); }
     std::vector<double> devf, devx;
     std::vector<u32> permf, permx;
-    if (p->use_f64) { devf.resize(dev.size() / 2); permf = ks_perm(p->logn, p->f64_loge); }
-    if (p->d_keys_x) { devx.resize(dev.size() / 2); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
+    if (p->use_f64) { devf.resize(words); permf = ks_perm(p->logn, p->f64_loge); }
+    if (p->d_keys_x) { devx.resize(words); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
     for (u64 d = 0; d < L; ++d) {
         if (!h_keys[d]) return HEXL_E_BADARG;
         for (u64 slot = 0; slot <= L; ++slot) {
@@ -297,11 +303,12 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
             for (u64 k = 0; k < 2; ++k) {
                 const u64* src = h_keys[d] + (k * K + i) * n;            // fpga.cpp:1186-1190
                 const size_t base = ((d * (L + 1) + slot) * 2 + k) * n;
-                for (u64 j = 0; j < n; ++j) {
-                    const u64 v = src[perm[j]] % q;
-                    dev[2 * base + j] = v;
-                    if (!p->use_f64) dev[2 * base + n + j] = (u64)(((u128)v << 64) / q);
-                }
+                if (!p->use_f64)
+                    for (u64 j = 0; j < n; ++j) {
+                        const u64 v = src[perm[j]] % q;
+                        dev[2 * base + j] = v;
+                        dev[2 * base + n + j] = (u64)(((u128)v << 64) / q);
+                    }
                 if (p->use_f64)                                          // same limb as centred doubles
                     for (u64 j = 0; j < n; ++j) {
                         const u64 v = src[permf[j]] % q;
@@ -316,7 +323,7 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
         }
     }
     HX_CHECK(hipStreamSynchronize(p->ctx->stream));
-    HX_CHECK(hipMemcpy(p->d_keys, dev.data(), dev.size() * sizeof(u64), hipMemcpyHostToDevice));
+    if (!p->use_f64) HX_CHECK(hipMemcpy(p->d_keys, dev.data(), dev.size() * sizeof(u64), hipMemcpyHostToDevice));
     if (p->use_f64)
         HX_CHECK(hipMemcpy(p->d_keys_f64, devf.data(), devf.size() * sizeof(double), hipMemcpyHostToDevice));
     if (p->d_keys_x)
@@ -334,6 +341,12 @@ extern "C" int hexl_keyswitch(hexl_ks_plan* p, uint64_t* d_result, const uint64_
 extern "C" int hexl_multiply_relinearize(hexl_ks_plan* p, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b,
                                          size_t batch) {
     if (!p || !d_out || !d_a || !d_b) return HEXL_E_BADARG;
+    // d_out is written while d_a / d_b are still being read (component 0 is stored before component 1's operands are loaded)
+    const size_t bytes = batch * 2 * size_t(p->L) * p->n * sizeof(u64);
+    auto overlaps = [&](const uint64_t* x) {
+        return (const char*)d_out < (const char*)x + bytes && (const char*)x < (const char*)d_out + bytes;
+    };
+    if (overlaps(d_a) || overlaps(d_b)) return HEXL_E_BADARG;
     HX_CHECK(hipSetDevice(p->ctx->device));
     return hx_launch_multiply_relinearize(p, d_out, d_a, d_b, batch);
 }

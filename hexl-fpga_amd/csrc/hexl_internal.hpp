@@ -109,6 +109,8 @@ struct hexl_ks_plan {
     size_t cap = 0;
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
+    u32* d_flag = nullptr;            // one device word + its pinned host mirror: input-range flag (HEXL_KS_VALIDATE)
+    u32* h_flag = nullptr;
     hipStream_t cur = nullptr;        // stream the chunk being launched goes to
     u64* cur_scratch = nullptr;
 };

@@ -448,15 +448,17 @@ __global__ void k_ks_validate(const u64* __restrict__ t, const u64* __restrict__
 }
 
 static int validate_inputs(hexl_ks_plan* p, const u64* d_result, const u64* d_t_target, size_t batch) {
-    u32* d_bad = nullptr;
-    HX_CHECK(hipMalloc((void**)&d_bad, sizeof(u32)));
-    HX_CHECK(hipMemsetAsync(d_bad, 0, sizeof(u32), p->ctx->stream));
-    hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, d_result, p->d_mods, p->L, p->n, batch, d_bad);
-    u32 bad = 0;
-    HX_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
+    // one flag word per plan, allocated once, with a pinned host mirror (no hipMalloc / hipFree per call, nothing to leak on
+    // an error path, no asynchronous copy into pageable memory)
+    if (!p->d_flag) {
+        HX_CHECK(hipMalloc((void**)&p->d_flag, sizeof(u32)));
+        HX_CHECK(hipHostMalloc((void**)&p->h_flag, sizeof(u32), hipHostMallocDefault));
+    }
+    HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), p->ctx->stream));
+    hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, d_result, p->d_mods, p->L, p->n, batch, p->d_flag);
+    HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
     HX_CHECK(hipStreamSynchronize(p->ctx->stream));
-    HX_CHECK(hipFree(d_bad));
-    return bad ? HEXL_E_RANGE : 0;
+    return *p->h_flag ? HEXL_E_RANGE : 0;
 }
 
 int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,

@@ -76,6 +76,8 @@ struct KsArgsX {
     const u64* t_target;     // [chunk][L][n]
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
+    u32 key_stride;          // words between key[d][slot] rows: 2 n. (Profiling aid HEXL_KSX_KEY_ALIAS=1, WRONG RESULTS: 0, every key
+                             // row reads row 0, which takes the key stream out of the L2-miss-side counters -- bench.py's DRAM-side estimate)
     // fused multiply + relinearize (hexl_multiply_relinearize): ciphertext pairs a, b [chunk][2][L][n]; the keyswitch input
     // is a_1 . b_1 (never stored) and `result` is WRITTEN with (a_0 b_0, a_0 b_1 + a_1 b_0) + keyswitch(a_1 b_1)
     const u64 *mul_a, *mul_b;
@@ -108,6 +110,12 @@ __device__ __forceinline__ XcdWalk xcd_walk(u32 total) {
     const u32 g = gridDim.x >> 3, q = total >> 3, r = total & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const u32 start = x * q + (x < r ? x : r);
     return XcdWalk{start + j, start + q + (x < r ? 1u : 0u), g};
+}
+
+// key[d][slot][0] (key[d][slot][1] follows it, n words further)
+template <class G>
+__device__ __forceinline__ const double* key_row(const KsArgsX& a, u32 d, u32 slot) {
+    return a.keys + size_t(d * (a.L + 1) + slot) * a.key_stride;
 }
 
 __device__ __forceinline__ u32 xcd_item_x(u32 bid, u32 total) {   // XCD-contiguous work ranges (keyswitch.hip)
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], msp.m);                 // intt1_redu.hpp:36-42
         KX_STAMP(4 * it + 1);
-        const double* k0 = a.keys + ((size_t(it) * (L + 1) + L) * 2) * G::N;
+        const double* k0 = key_row<G>(a, it, L);
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
         KX_STAMP(4 * it + 2);
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const double* k0 = a.keys + ((size_t(i) * (L + 1) + i) * 2) * G::N;
+        const double* k0 = key_row<G>(a, i, i);
         KX_STAMP(60);
         if constexpr (!FUSED && G::KL <= 2 && KX_FIRST_DIRECT) {
             KX_STAMP(61);
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         KX_STAMP(4 * it + 1);
         u32 nit = it + 1;
         if (nit == i) ++nit;
-        const double* k0 = a.keys + ((size_t(it) * (L + 1) + i) * 2) * G::N;
+        const double* k0 = key_row<G>(a, it, i);
         W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
         KX_STAMP(4 * it + 2);
         mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, round_src(nit), tid, m);   // nit <= L: s'_0 follows the last c_d
@@ -621,6 +629,8 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = a.mul_b = nullptr;
     a.stamps = nullptr;
+    static const u32 alias = [] { const char* e = getenv("HEXL_KSX_KEY_ALIAS"); return (e && atoi(e) == 1) ? 1u : 0u; }();
+    a.key_stride = alias ? 0u : u32(2 * n);
     switch (p->logn) {
         case 10: return launch_x_small<10>(p, a, stage_mask, ev);
         case 11: return launch_x_small<11>(p, a, stage_mask, ev);
@@ -652,6 +662,7 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = d_a; a.mul_b = d_b;
     a.stamps = nullptr;
+    a.key_stride = u32(2 * n);
     // (moduli small enough for the longer lazy periods run with period 3 here: always valid, two fewer kernel variants)
     return p->f64_lazy ? run_chunk_x<14, 4, 3, true>(p, a, 7, nullptr) : run_chunk_x<14, 4, 0, true>(p, a, 7, nullptr);
 }

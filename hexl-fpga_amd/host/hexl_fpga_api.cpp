@@ -13,7 +13,13 @@
 //     fpga_int.cpp:346-353,429-447) -- and pushes it through the device's staging pipeline while the caller keeps
 //     enqueuing. Each device context is touched by its own runner only.
 //   * XCompleted() waits on a condition variable until every object of that primitive is done (the reference
-//     spins on ready_, fpga_int.cpp:484-507), returns true and resets the worksize to 1.
+//     spins on ready_, fpga_int.cpp:484-507), returns true and resets the worksize to 1. Completion is tracked PER
+//     OBJECT: every object carries a ticket of its primitive, a finished run retires its ticket range, and a waiter
+//     (a worksize-1 call, XCompleted) returns when every ticket up to its own is retired -- with several devices
+//     runs finish out of order, a bare counter would let a caller return while its own object is still in flight.
+//   * a runner does not start on the first object of a batch window that is still being filled: it waits (bounded)
+//     for its share -- worksize / devices -- or for the window to close (the worksize reached, XCompleted called, a
+//     different parameter set queued behind the run).
 //   * several devices take contiguous shares of a run. Objects whose OUTPUT array is still being produced on
 //     another device wait for it (KeySwitch accumulates into `result`; benchmark/bench_keyswitch.cpp:113-131
 //     submits the same result many times), and runs of different primitives never overlap, so the results are
@@ -24,6 +30,7 @@
 #include "../../include/hexl-fpga.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -89,11 +96,16 @@ struct Obj {
     const uint64_t *p0, *p1, *p2;
     uint64_t n, s0, s1, s2;
     int plan;
+    uint64_t ticket = 0;         // 1-based sequence number among the objects of this primitive (set by submit)
 };
 
 struct Device {
     hexl_ctx* ctx = nullptr;
-    std::map<int, hexl_ks_plan*> plans;        // by Engine::ks_keys index; touched by this device's runner only
+    // by Engine::ks_keys index; touched by this device's runner only. Bounded (HEXL_PLAN_CACHE, default 8 parameter/key
+    // sets per device): a long-running application that rotates keys would otherwise pin tables, three key copies and
+    // scratch for every key set it has ever used -- the least recently used plan is destroyed when a new one is needed.
+    std::map<int, hexl_ks_plan*> plans;
+    std::vector<int> plan_lru;                 // most recent last
     std::thread runner;
 };
 
@@ -104,7 +116,13 @@ struct Engine {
     std::mutex mu;                  // guards everything below
     std::condition_variable cv_work, cv_done;
     std::deque<Obj> fifo;
-    uint64_t ws[NKIND] = {1, 1, 1, 1}, submitted[NKIND] = {0, 0, 0, 0}, completed[NKIND] = {0, 0, 0, 0};
+    size_t max_plans = 8;           // HEXL_PLAN_CACHE: device-side keyswitch plans kept per device
+    uint64_t ws[NKIND] = {1, 1, 1, 1}, submitted[NKIND] = {0, 0, 0, 0};
+    // per-object completion: retired[k] = every ticket <= it is done; finished ranges beyond it wait in `done_ranges`
+    uint64_t retired[NKIND] = {0, 0, 0, 0};
+    std::map<uint64_t, uint64_t> done_ranges[NKIND];             // first ticket -> last ticket of a finished run
+    uint64_t window_open[NKIND] = {0, 0, 0, 0};                  // objects the current worksize window still expects
+    int closers[NKIND] = {0, 0, 0, 0};                           // XCompleted() callers waiting: the window is closed
     int running_kind = -1, running_runs = 0;                     // runs in flight (all of one primitive)
     std::unordered_map<const void*, int> inflight_out;           // output arrays of the runs in flight
     bool stop = false;
@@ -133,16 +151,29 @@ bool same_params(const Obj& a, const Obj& b) {
 }
 
 hexl_ks_plan* plan_for(Engine& e, Device& dev, int idx) {
+    auto touch = [&] {
+        auto& l = dev.plan_lru;
+        l.erase(std::remove(l.begin(), l.end(), idx), l.end());
+        l.push_back(idx);
+    };
     auto it = dev.plans.find(idx);
-    if (it != dev.plans.end()) return it->second;
+    if (it != dev.plans.end()) { touch(); return it->second; }
     KsKey k;
-    { std::lock_guard<std::mutex> lk(e.mu); k = e.ks_keys[idx]; }
+    size_t keep;
+    { std::lock_guard<std::mutex> lk(e.mu); k = e.ks_keys[idx]; keep = e.max_plans; }
+    while (dev.plans.size() >= keep && !dev.plan_lru.empty()) {   // evict the least recently used plan of this device
+        const int old = dev.plan_lru.front();
+        dev.plan_lru.erase(dev.plan_lru.begin());
+        auto o = dev.plans.find(old);
+        if (o != dev.plans.end()) { hexl_ks_plan_destroy(o->second); dev.plans.erase(o); }
+    }
     hexl_ks_plan* p = nullptr;
     int rc = hexl_ks_plan_create(dev.ctx, k.n, k.L, k.K, k.rns, 2, k.moduli.data(), k.msf.data(), k.twiddles, &p);
     if (rc) die("hexl_ks_plan_create (unsupported keyswitch parameters?)", rc);
     rc = hexl_ks_set_keys(p, k.keys.data());
     if (rc) die("hexl_ks_set_keys", rc);
     dev.plans.emplace(idx, p);
+    touch();
     return p;
 }
 
@@ -187,24 +218,48 @@ void runner_loop(Engine* ep, size_t di) {
     Device& dev = e.devs[di];
     std::vector<Obj> run;
     std::unique_lock<std::mutex> lk(e.mu);
+    const size_t nd = e.devs.size();
     for (;;) {
         run.clear();
-        e.cv_work.wait(lk, [&] {
-            if (e.stop) return true;
-            if (e.fifo.empty()) return false;
+        // the head run: same primitive, same parameters, no output another device is still producing
+        auto head_run = [&]() -> size_t {
+            if (e.fifo.empty()) return 0;
             const Obj& h = e.fifo.front();
-            if (e.running_runs > 0 && e.running_kind != (int)h.kind) return false;      // primitives never overlap
-            return e.inflight_out.find(h.out) == e.inflight_out.end();                   // output busy on another device
-        });
-        if (e.stop) return;
-        // the head run: same primitive, same parameters, no output another device is still producing. With several
-        // devices a runner leaves the others their share of what is queued right now.
-        size_t avail = 0;
-        while (avail < e.fifo.size() && avail < e.max_run && same_params(e.fifo.front(), e.fifo[avail]) &&
-               e.inflight_out.find(e.fifo[avail].out) == e.inflight_out.end())
-            ++avail;
-        const size_t nd = e.devs.size();
-        const size_t take = nd > 1 ? std::max<size_t>(1, (avail + nd - 1) / nd) : avail;
+            if (e.running_runs > 0 && e.running_kind != (int)h.kind) return 0;          // primitives never overlap
+            size_t avail = 0;
+            while (avail < e.fifo.size() && avail < e.max_run && same_params(h, e.fifo[avail]) &&
+                   e.inflight_out.find(e.fifo[avail].out) == e.inflight_out.end())
+                ++avail;
+            return avail;
+        };
+        size_t avail = 0, take = 0;
+        for (bool timed_out = false;;) {
+            if (e.stop) return;
+            avail = head_run();
+            if (avail) {
+                const Kind k = e.fifo.front().kind;
+                // this runner's share of the batch window: worksize / devices (everything, for one device)
+                const uint64_t ws = e.ws[k];
+                const size_t share = std::min<size_t>(e.max_run, nd > 1 ? (size_t)((ws + nd - 1) / nd) : (size_t)ws);
+                // closed: nothing more will join this run -- the window is full, XCompleted() is waiting, the run is cut short
+                // by an object it cannot absorb, or the caller went quiet for longer than the bounded wait below
+                const bool closed = e.window_open[k] == 0 || e.closers[k] > 0 || avail < e.fifo.size() || avail >= e.max_run || timed_out;
+                if (avail >= share) { take = nd > 1 ? share : avail; break; }
+                if (closed) {
+                    // the remainder of a window: split it between the devices, but not into crumbs (a run has a fixed cost of
+                    // a few hundred microseconds: staging pipeline, launches, synchronisation)
+                    take = nd > 1 ? std::min(avail, std::max<size_t>(4, (avail + nd - 1) / nd)) : avail;
+                    break;
+                }
+                // a window that is still being filled: objects arrive microseconds apart, wait for the share (bounded)
+                // (system_clock: pthread_cond_timedwait, which ThreadSanitizer intercepts; wait_for's steady clock is not)
+                timed_out = e.cv_work.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(500)) ==
+                            std::cv_status::timeout;
+                continue;
+            }
+            timed_out = false;
+            e.cv_work.wait(lk);
+        }
         for (size_t k = 0; k < take; ++k) { run.push_back(e.fifo.front()); e.fifo.pop_front(); }
         for (const Obj& o : run) ++e.inflight_out[o.out];
         e.running_kind = (int)run.front().kind;
@@ -220,28 +275,39 @@ void runner_loop(Engine* ep, size_t di) {
             auto it = e.inflight_out.find(o.out);
             if (--it->second == 0) e.inflight_out.erase(it);
         }
-        e.completed[run.front().kind] += run.size();
+        // retire the run's tickets (contiguous: a run is consecutive objects of one primitive in submission order)
+        const Kind k = run.front().kind;
+        e.done_ranges[k][run.front().ticket] = run.back().ticket;
+        for (auto it = e.done_ranges[k].begin(); it != e.done_ranges[k].end() && it->first == e.retired[k] + 1;
+             it = e.done_ranges[k].erase(it))
+            e.retired[k] = it->second;
         --e.running_runs;
         e.cv_done.notify_all();
         e.cv_work.notify_all();
     }
 }
 
-// append one object; worksize 1 => wait for it (fpga_int.cpp:459-461)
-void submit(Engine& e, const Obj& o) {
+// append one object; worksize 1 => wait for it (fpga_int.cpp:459-461) -- for ITS ticket, not for a count of finished objects
+void submit(Engine& e, Obj o) {
     std::unique_lock<std::mutex> lk(e.mu);
+    o.ticket = ++e.submitted[o.kind];
+    const uint64_t mine = o.ticket;
     e.fifo.push_back(o);
-    const uint64_t mine = ++e.submitted[o.kind];
-    e.cv_work.notify_one();
-    if (e.ws[o.kind] == 1) e.cv_done.wait(lk, [&] { return e.completed[o.kind] >= mine; });
+    if (e.window_open[o.kind]) --e.window_open[o.kind];
+    e.cv_work.notify_all();
+    if (e.ws[o.kind] == 1) e.cv_done.wait(lk, [&] { return e.retired[o.kind] >= mine; });
 }
 
 bool completed(Kind k) {
     Engine& e = eng();
     std::unique_lock<std::mutex> lk(e.mu);
     const uint64_t upto = e.submitted[k];
-    e.cv_done.wait(lk, [&] { return e.completed[k] >= upto; });
+    ++e.closers[k];                                                // the window is closed: runners stop waiting for more
+    e.cv_work.notify_all();
+    e.cv_done.wait(lk, [&] { return e.retired[k] >= upto; });
+    --e.closers[k];
     e.ws[k] = 1;                                                   // fpga_int.cpp:229,308,389,504
+    e.window_open[k] = 0;
     return true;
 }
 
@@ -249,6 +315,7 @@ void set_ws(Kind k, uint64_t ws) {
     Engine& e = eng();
     std::lock_guard<std::mutex> lk(e.mu);
     e.ws[k] = ws ? ws : 1;
+    e.window_open[k] = e.ws[k] > 1 ? e.ws[k] : 0;                  // objects this window still expects
 }
 
 bool pow2_in(uint64_t n, uint64_t lo, uint64_t hi) { return n >= lo && n <= hi && (n & (n - 1)) == 0; }
@@ -264,6 +331,8 @@ void acquire_FPGA_resources() {
     e->debug = (int)env_ul("FPGA_DEBUG", 0);
     e->max_run = env_ul("FPGA_BUFSIZE", 1024);
     if (e->max_run == 0) e->max_run = 1;
+    e->max_plans = env_ul("HEXL_PLAN_CACHE", 8);
+    if (e->max_plans == 0) e->max_plans = 1;
     // RUN_CHOICE (0 CPU / 1 emulator / 2 FPGA in the reference, fpga_int.cpp:40-60) has one meaning here:
     // the MI355X path. There is deliberately no CPU fallback.
     const unsigned long want = env_ul("NUM_DEV", 1);

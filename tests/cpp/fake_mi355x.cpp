@@ -37,9 +37,12 @@ struct Busy {   // aborts if two threads are inside one context at once
     }
     ~Busy() { c->busy.fetch_sub(1); }
 };
-void work_delay() {   // FAKE_DELAY_US: make runs long enough for the caller / other runners to interleave
+// FAKE_DELAY_US: make runs long enough for the caller / other runners to interleave; FAKE_DELAY_DEV0_X: device 0 that many
+// times slower, so that runs complete OUT OF ORDER across devices (per-object completion, tests/cpp/test_cxx_api.cpp threads)
+void work_delay(const hexl_ctx* c) {
     static const long us = [] { const char* e = std::getenv("FAKE_DELAY_US"); return e ? atol(e) : 0L; }();
-    if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us));
+    static const long x0 = [] { const char* e = std::getenv("FAKE_DELAY_DEV0_X"); return e ? atol(e) : 1L; }();
+    if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us * (c->device == 0 ? x0 : 1)));
 }
 }  // namespace
 
@@ -67,21 +70,21 @@ int hexl_ctx_describe(hexl_ctx* c, char* buf, size_t len) {
 int hexl_ntt_fwd_host(hexl_ctx* c, uint64_t* const* x, size_t batch, const uint64_t* roots, const uint64_t* precon, uint64_t q,
                       uint64_t n) {
     Busy b(c);
-    work_delay();
+    work_delay(c);                                                 // delay BEFORE the compute: a caller released early sees stale data
     for (size_t k = 0; k < batch; ++k) orc_ntt_fwd(x[k], n, q, roots, precon);
     return 0;
 }
 int hexl_ntt_inv_host(hexl_ctx* c, uint64_t* const* x, size_t batch, const uint64_t* ir, const uint64_t* ip, uint64_t q,
                       uint64_t inv_n, uint64_t inv_n_w, uint64_t n) {
     Busy b(c);
-    work_delay();
+    work_delay(c);
     for (size_t k = 0; k < batch; ++k) orc_ntt_inv(x[k], n, q, ir, ip, inv_n, inv_n_w);
     return 0;
 }
 int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* out, const uint64_t* const* a, const uint64_t* const* bb, size_t batch,
                               uint64_t n, const uint64_t* const* moduli, uint64_t nm) {
     Busy b(c);
-    work_delay();
+    work_delay(c);
     for (size_t k = 0; k < batch; ++k) orc_dyadic_multiply(out[k], a[k], bb[k], n, moduli[k], nm, 1);
     return 0;
 }
@@ -108,7 +111,7 @@ int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* keys) {
 int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* results, const uint64_t* const* ts, size_t batch) {
     if (p->keys.empty()) return HEXL_E_NOKEYS;
     Busy b(p->ctx);
-    work_delay();
+    work_delay(p->ctx);
     std::vector<const uint64_t*> kp;
     for (auto& k : p->keys) kp.push_back(k.data());
     for (size_t k = 0; k < batch; ++k) {        // plain (non-atomic) read-modify-write of the caller's result, like the product

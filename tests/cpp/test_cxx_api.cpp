@@ -198,8 +198,39 @@ static void test_mixed_and_fences() {
     CHECK(xa == ea && xb == eb, "NTT fence on modulus change");
 }
 
+// Several caller threads, worksize 1 each (what concurrent SEAL evaluators do): X() must not return before ITS object is
+// done. With several devices runs finish out of order; a completion COUNTER would release a caller whose own object is
+// still running on a slower device (per-object tickets: hexl_fpga_api.cpp submit / runner_loop).
+#include <thread>
+static void test_concurrent_worksize1(int threads, int rounds) {
+    uint64_t q;
+    orc_generate_primes(&q, 1, 50, 16384);
+    Tables t(16384, q);
+    std::vector<int> bad(threads, 0);
+    std::vector<std::thread> th;
+    for (int id = 0; id < threads; ++id)
+        th.emplace_back([&, id] {
+            vec x(16384), ref;
+            for (int r = 0; r < rounds; ++r) {
+                orc_fill_splitmix(x.data(), 16384, 1000 * id + r, q);
+                ref = x;
+                orc_ntt_fwd(ref.data(), 16384, q, t.roots.data(), t.precon.data());
+                _NTT(x.data(), t.roots.data(), t.precon.data(), q, 16384);     // worksize 1: done when it returns
+                if (x != ref) ++bad[id];
+            }
+        });
+    for (auto& x : th) x.join();
+    for (int id = 0; id < threads; ++id) CHECK(bad[id] == 0, "thread %d saw %d unfinished worksize-1 results", id, bad[id]);
+}
+
 int main(int argc, char** argv) {
     acquire_FPGA_resources();
+    if (argc > 1 && !std::strcmp(argv[1], "threads")) {           // concurrent worksize-1 callers: threads [count] [rounds]
+        test_concurrent_worksize1(argc > 2 ? atoi(argv[2]) : 4, argc > 3 ? atoi(argv[3]) : 20);
+        release_FPGA_resources();
+        std::printf(failures ? "CXX API: %d FAILURE(S)\n" : "CXX API: ALL PASSED\n", failures);
+        return failures ? 1 : 0;
+    }
     if (argc > 1 && !std::strcmp(argv[1], "alias")) {             // the ordering stress on its own: alias [repeats]
         test_keyswitch_aliased_across_subbatches(argc > 2 ? atoi(argv[2]) : 50);
         release_FPGA_resources();

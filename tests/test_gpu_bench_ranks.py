@@ -1,7 +1,9 @@
 """GPU: the N > 1 path of bench.py executed the way the driver launches it (torch.distributed.run, one process per rank,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) -- on the one GPU this box has: HEXL_BENCH_ONE_GPU=1 puts
-both ranks on GPU 0 and routes the timing barrier and the max-reduce through gloo. What it pins: every rank builds its own
-plan and shard, both pass the in-run oracle check, rank 0 alone prints ONE JSON line whose value is the whole-job rate."""
+both ranks on GPU 0 and routes the timing barrier and the max-reduce through gloo. What it pins: BASELINE config 5's shape
+(ONE batch per step split into contiguous shards, `scaling: "strong"`; 2048 over two ranks = the 1024 per GPU of 8192 over
+eight), every rank passing the in-run oracle check on both sides of a scratch-chunk boundary, rank 0 alone printing ONE JSON
+line whose value is the whole-job rate, the all-ranks NTT rate (BASELINE's second metric), and the weak mode of --batch."""
 import json
 import os
 import subprocess
@@ -14,19 +16,34 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def test_two_ranks_one_json_line():
+def run_ranks(port, *args):
     env = dict(os.environ, HEXL_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512",
-           "--no-extra", "--no-cpu"]
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", *args]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     print(out.stdout[-2000:], out.stderr[-2000:])
     assert out.returncode == 0
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["verified_vs_oracle"] is True
+    return json.loads(lines[0])
+
+
+def test_two_ranks_strong_shape_of_config_5():
+    d = run_ranks(29517, "--total-batch", "2048", "--barrier-per-step")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["verified_vs_oracle"] is True
+    assert d["config"]["global_batch"] == 2048 and d["config"]["batch_per_gpu"] == 1024      # 1024 per rank: config 5's shard
+    assert d["verified_instances"] == [0, 255, 256, 1023]
     assert d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
-    # whole-job aggregate: 2 ranks x 512 keyswitches x 3 steps over the slowest rank's wall time
-    assert abs(d["value"] - 2 * 512 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    # whole-job aggregate: 2048 keyswitches x 3 steps over the slowest rank's wall time
+    assert abs(d["value"] - 2048 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    ntt = d["extra"]["ntt_N16384_batch1024"]
+    for leg in ("fwd", "inv"):                                   # BASELINE's second metric at N ranks: all ranks' transforms
+        assert ntt[leg]["n_gpus"] == 2 and ntt[leg]["ntt_per_s_all_ranks"] > 0
+
+
+def test_two_ranks_weak_mode():
+    d = run_ranks(29519, "--batch", "512", "--no-extra")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["verified_vs_oracle"] is True
+    assert d["config"]["global_batch"] == 1024 and d["config"]["batch_per_gpu"] == 512
+    assert abs(d["value"] - 2 * 512 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6

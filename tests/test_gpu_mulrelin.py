@@ -57,3 +57,21 @@ def test_rejects_what_it_does_not_cover(hx, ctx, dev, orc):
     with pytest.raises(hx.HexlError):
         plan.multiply_relinearize(z, z, z, 1)
     plan.close()
+
+
+def test_rejects_output_aliasing_an_operand(hx, ctx, dev, orc):
+    """d_out is written while the operands are still being read (component 0 is stored before component 1's operands are
+    loaded): overlap with d_a or d_b is refused instead of silently producing a wrong ciphertext"""
+    n, L, K = 16384, 2, 3
+    case = KsCase(orc, n, L, K, seed=3)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    import torch
+    a = torch.zeros(2 * 2 * L * n, dtype=torch.int64, device=dev)
+    b = torch.zeros(2 * L * n, dtype=torch.int64, device=dev)
+    for out, x, y in ((a[:2 * L * n], a[:2 * L * n], b), (a[:2 * L * n], b, a[:2 * L * n]), (a[n:n + 2 * L * n], a[:2 * L * n], b)):
+        with pytest.raises(hx.HexlError):
+            plan.multiply_relinearize(out, x, y, 1)
+    plan.multiply_relinearize(a[2 * L * n:], a[:2 * L * n], b, 1)       # adjacent, not overlapping: accepted
+    ctx.sync()
+    plan.close()

@@ -43,3 +43,10 @@ def test_debug_trace_and_small_runs(exe):
     """FPGA_DEBUG=1 prints one line per run; FPGA_BUFSIZE=1 forces one object per run (host/src/fpga_int.cpp:123-129)"""
     out = run(exe, ["alias", "1"], NUM_DEV=2, FPGA_DEBUG=1, FPGA_BUFSIZE=1)
     assert "x KeySwitch" in out.stderr
+
+
+def test_concurrent_worksize1_callers_wait_for_their_own_object(exe):
+    """with NUM_DEV > 1 and several submitting threads a worksize-1 call must not return before ITS object is
+    done. Device 0 is 8x slower here, so later objects on the other devices finish first -- a completion counter would
+    release the caller early; tickets retire in order."""
+    run(exe, ["threads", "4", "15"], NUM_DEV=3, FAKE_DELAY_US=300, FAKE_DELAY_DEV0_X=8)

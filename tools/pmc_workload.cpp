@@ -1,0 +1,100 @@
+// pmc_workload.cpp -- native workload for rocprofv3 passes (kernel trace or one PMC group per run): `reps` launches of
+// hexl_keyswitch at batch B (device-resident synthetic data, words uniform below their modulus) through the C-ABI, and
+// optionally `reps` forward + inverse NTT launches at batch 1024. Starts in a fraction of a second (no Python), so
+// bench.py can afford to run the PMC passes of its roofline block INSIDE the benchmark run.
+//   usage: pmc_workload <batch> <L> [reps = 2] [ntt = 0|1]
+// Data are synthetic and nothing is checked here: parity is the test suite's job, this only feeds counters.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../include/hexl_mi355x.h"
+
+#define CK(e) do { int rc_ = (int)(e); if (rc_) { std::fprintf(stderr, "%s failed: %d\n", #e, rc_); return 1; } } while (0)
+
+static uint64_t sm_state = 7;
+static uint64_t sm() {
+    uint64_t z = (sm_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t powmod(uint64_t a, uint64_t e, uint64_t q) {
+    unsigned __int128 r = 1, b = a % q;
+    for (; e; e >>= 1, b = b * b % q) if (e & 1) r = r * b % q;
+    return (uint64_t)r;
+}
+
+int main(int argc, char** argv) {
+    const size_t batch = argc > 1 ? (size_t)atol(argv[1]) : 256;
+    const uint64_t n = 16384, L = argc > 2 ? (uint64_t)atoi(argv[2]) : 7, K = L + 1;
+    const int reps = argc > 3 ? atoi(argv[3]) : 2, with_ntt = argc > 4 ? atoi(argv[4]) : 0;
+    // GeneratePrimes(8, 51, 16384) of the reference's test utilities: 51-bit primes, 1 mod 2n
+    const uint64_t primes[8] = {2251799814045697ull, 2251799814799361ull, 2251799814930433ull, 2251799815094273ull,
+                                2251799815487489ull, 2251799815520257ull, 2251799816273921ull, 2251799816568833ull};
+    if (L < 1 || K > 8 || !batch) { std::fprintf(stderr, "usage: pmc_workload <batch> <L <= 7> [reps] [ntt]\n"); return 2; }
+    std::vector<uint64_t> moduli(primes, primes + K), msf(K, 1);
+    for (uint64_t i = 0; i + 1 < K; ++i) msf[i] = powmod(moduli[K - 1] % moduli[i], moduli[i] - 2, moduli[i]);
+    hexl_ctx* ctx = nullptr;
+    CK(hexl_ctx_create(0, &ctx));
+    hexl_ks_plan* plan = nullptr;
+    CK(hexl_ks_plan_create(ctx, n, L, K, K, 2, moduli.data(), msf.data(), nullptr, &plan));
+    std::vector<std::vector<uint64_t>> keys(L, std::vector<uint64_t>(2 * K * n));
+    std::vector<const uint64_t*> kp;
+    for (auto& k : keys) {
+        for (uint64_t kk = 0; kk < 2; ++kk)
+            for (uint64_t i = 0; i < K; ++i)
+                for (uint64_t j = 0; j < n; ++j) k[(kk * K + i) * n + j] = sm() % moduli[i];
+        kp.push_back(k.data());
+    }
+    CK(hexl_ks_set_keys(plan, kp.data()));
+    // four distinct instances, replicated over the batch on the device
+    const size_t tw = L * n, rw = 2 * L * n, distinct = batch < 4 ? batch : 4;
+    std::vector<uint64_t> ht(distinct * tw), hr(distinct * rw);
+    for (size_t b = 0; b < distinct; ++b) {
+        for (uint64_t d = 0; d < L; ++d) for (uint64_t j = 0; j < n; ++j) ht[b * tw + d * n + j] = sm() % moduli[d];
+        for (uint64_t x = 0; x < 2 * L; ++x) for (uint64_t j = 0; j < n; ++j) hr[b * rw + x * n + j] = sm() % moduli[x % L];
+    }
+    uint64_t *dt = nullptr, *dr = nullptr;
+    CK(hipMalloc((void**)&dt, batch * tw * 8));
+    CK(hipMalloc((void**)&dr, batch * rw * 8));
+    CK(hipMemcpy(dt, ht.data(), distinct * tw * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dr, hr.data(), distinct * rw * 8, hipMemcpyHostToDevice));
+    for (size_t have = distinct; have < batch; have *= 2) {
+        const size_t cnt = have * 2 <= batch ? have : batch - have;
+        CK(hipMemcpy(dt + have * tw, dt, cnt * tw * 8, hipMemcpyDeviceToDevice));
+        CK(hipMemcpy(dr + have * rw, dr, cnt * rw * 8, hipMemcpyDeviceToDevice));
+    }
+    for (int r = 0; r < reps; ++r) CK(hexl_keyswitch(plan, dr, dt, batch));
+    CK(hexl_ctx_sync(ctx));
+    if (with_ntt) {
+        // tables need not be genuine for counters, but genuine Shoup pairs keep the exact FP64 fast path (ntt.hip) in play
+        const uint64_t q = moduli[0], nb = 1024;
+        std::vector<uint64_t> roots(n), precon(n);
+        for (uint64_t j = 0; j < n; ++j) {
+            roots[j] = sm() % q;
+            precon[j] = (uint64_t)(((unsigned __int128)roots[j] << 64) / q);
+        }
+        uint64_t *dx = nullptr, *dro = nullptr, *dpr = nullptr;
+        CK(hipMalloc((void**)&dx, nb * n * 8));
+        CK(hipMalloc((void**)&dro, n * 8));
+        CK(hipMalloc((void**)&dpr, n * 8));
+        CK(hipMemcpy(dro, roots.data(), n * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dpr, precon.data(), n * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dx, dt, (nb * n <= batch * tw ? nb * n : batch * tw) * 8, hipMemcpyDeviceToDevice));
+        for (int r = 0; r < reps; ++r) {
+            CK(hexl_ntt_fwd(ctx, dx, nb, dro, dpr, q, n));
+            CK(hexl_ntt_inv(ctx, dx, nb, dro, dpr, q, 1, 1, n));
+        }
+        CK(hexl_ctx_sync(ctx));
+        (void)hipFree(dx); (void)hipFree(dro); (void)hipFree(dpr);
+    }
+    CK(hexl_ks_plan_destroy(plan));
+    (void)hipFree(dt); (void)hipFree(dr);
+    CK(hexl_ctx_destroy(ctx));
+    std::printf("pmc_workload: %d x keyswitch batch %zu L=%lu%s done\n", reps, batch, (unsigned long)L, with_ntt ? " + NTT" : "");
+    return 0;
+}
