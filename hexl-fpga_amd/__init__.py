@@ -24,7 +24,8 @@ import numpy as np
 
 _PKG = Path(__file__).resolve().parent
 ROOT = _PKG.parent
-LIB_PATH = _PKG / "lib" / "libhexl_mi355x.so"
+# HEXL_MI355X_LIB: another build of the same library (tools/build_variant.sh: kernel experiments side by side on one box)
+LIB_PATH = Path(os.environ["HEXL_MI355X_LIB"]) if os.environ.get("HEXL_MI355X_LIB") else _PKG / "lib" / "libhexl_mi355x.so"
 
 _u64 = ctypes.c_uint64
 _sz = ctypes.c_size_t

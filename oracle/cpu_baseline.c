@@ -9,7 +9,13 @@
  * orc_keyswitch returns (tests/test_cpu_baseline.py) -- only faster: ~6x one thread of the line-by-line oracle, which
  * divides 128-bit products and rebuilds its tables on every call.
  *
- * Not vectorised by hand (no AVX-512 IFMA like HEXL's production kernels): kind = "port".
+ * Vector code, selected at run time like HEXL selects its kernels (its NTT: AVX512-IFMA with 52-bit Shoup factors for moduli
+ * below 2^50, AVX512-DQ with 64-bit lanes and an emulated 64x64 high product above, scalar otherwise): the same two kernel
+ * families are written out below with intrinsics (butterflies on 8 lanes; the three narrow stages through lane permutes;
+ * the element-wise mod-up / multiply-accumulate / mod-down loops as well) when the compiler targets a host that has them
+ * (-march=native on the box that runs the benchmark). cb_isa() says which one a plan uses; HEXL_CPU_ISA=scalar forces the
+ * scalar port. Every path is lazy inside and fully reduced at the end, so all of them return the oracle's words.
+ * kind = "port+avx512ifma" / "port+avx512dq" / "port" in the bench line.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -28,6 +34,8 @@ typedef struct {
     uint64_t msf, msf_p, half_mod, fix;
     uint64_t *w, *wp;              /* forward roots (bit-reversed, index m+i) + Shoup factors */
     uint64_t *iw, *iwp;            /* inverse roots in stage order from index 0 + Shoup factors */
+    int isa;                       /* 0 scalar, 1 AVX512-DQ 64-bit lanes, 2 AVX512-IFMA (q < 2^50): all *_p factors are then */
+                                   /* floor(. * 2^52 / q) instead of floor(. * 2^64 / q) */
 } cb_mod;
 
 struct cb_plan {
@@ -45,7 +53,7 @@ static inline uint64_t csub(uint64_t x, uint64_t q) { return x >= q ? x - q : x;
 static inline uint64_t barrett1(uint64_t x, const cb_mod* m) { return csub(x - mulhi(x, m->barr_hi) * m->q, m->q); }
 
 /* Harvey forward NTT, inputs < q (or < 4q), outputs fully reduced; tests/test_utils/ntt.cpp:474-548 */
-static void fwd_ntt(uint64_t* x, uint64_t n, const cb_mod* m) {
+static void fwd_ntt_scalar(uint64_t* x, uint64_t n, const cb_mod* m) {
     const uint64_t q = m->q, twoq = m->twoq;
     uint64_t t = n >> 1;
     for (uint64_t mm = 1; mm < n; mm <<= 1, t >>= 1)
@@ -63,7 +71,7 @@ static void fwd_ntt(uint64_t* x, uint64_t n, const cb_mod* m) {
 }
 
 /* Harvey inverse NTT (Gentleman-Sande), scaled by n^-1, outputs in [0, q); ntt.cpp:580-659 */
-static void inv_ntt(uint64_t* x, uint64_t n, const cb_mod* m) {
+static void inv_ntt_scalar(uint64_t* x, uint64_t n, const cb_mod* m) {
     const uint64_t q = m->q, twoq = m->twoq;
     uint64_t t = 1, acc = 0;
     for (uint64_t mm = n >> 1; mm >= 1; mm >>= 1, t <<= 1) {
@@ -82,6 +90,146 @@ static void inv_ntt(uint64_t* x, uint64_t n, const cb_mod* m) {
     for (uint64_t j = 0; j < n; j++) x[j] = csub(mul_shoup_lazy(x[j], m->inv_n, m->inv_n_p, q), q);
 }
 
+
+/* ------------------------------------------------------------------------------------------------ AVX-512 kernels */
+#if defined(__AVX512F__) && defined(__AVX512DQ__)
+#include <immintrin.h>
+#define CB_AVX512 1
+#if defined(__AVX512IFMA__)
+#define CB_IFMA 1
+#endif
+typedef __m512i v8;
+#define VSET(x) _mm512_set1_epi64((long long)(x))
+#define VLD(p) _mm512_loadu_si512((const void*)(p))
+#define VST(p, v) _mm512_storeu_si512((void*)(p), (v))
+/* x in [0, 2m) -> [0, m): min(x, x - m) as unsigned (x - m wraps above x when x < m) */
+static inline v8 v_csub(v8 x, v8 m) { return _mm512_min_epu64(x, _mm512_sub_epi64(x, m)); }
+/* high 64 bits of the 64x64 product from four 32x32 products (what HEXL's 64-bit AVX512-DQ kernels do) */
+static inline v8 v_mulhi64(v8 a, v8 b) {
+    const v8 lo32 = VSET(0xffffffffull);
+    const v8 ah = _mm512_srli_epi64(a, 32), bh = _mm512_srli_epi64(b, 32);
+    const v8 w0 = _mm512_mul_epu32(a, b), w1 = _mm512_mul_epu32(a, bh), w2 = _mm512_mul_epu32(ah, b), w3 = _mm512_mul_epu32(ah, bh);
+    const v8 s1 = _mm512_add_epi64(w1, _mm512_srli_epi64(w0, 32));
+    const v8 s2 = _mm512_add_epi64(w2, _mm512_and_si512(s1, lo32));
+    return _mm512_add_epi64(_mm512_add_epi64(w3, _mm512_srli_epi64(s1, 32)), _mm512_srli_epi64(s2, 32));
+}
+/* x*w mod q in [0, 2q), Shoup form. IFMA: x, w < 2^52, wp = floor(w 2^52 / q), q < 2^50; else wp = floor(w 2^64 / q) */
+static inline __attribute__((always_inline)) v8 v_mul_shoup_lazy(v8 x, v8 w, v8 wp, v8 q, const int ifma) {
+#ifdef CB_IFMA
+    if (ifma) {
+        const v8 z = _mm512_setzero_si512();
+        const v8 qh = _mm512_madd52hi_epu64(z, x, wp);
+        const v8 d = _mm512_sub_epi64(_mm512_madd52lo_epu64(z, x, w), _mm512_madd52lo_epu64(z, qh, q));
+        return _mm512_and_si512(d, VSET((1ull << 52) - 1));
+    }
+#endif
+    (void)ifma;
+    return _mm512_sub_epi64(_mm512_mullo_epi64(w, x), _mm512_mullo_epi64(v_mulhi64(x, wp), q));
+}
+/* the three narrow stages pair coefficients inside a block of 16: lane permutes between (A = x[0..7], B = x[8..15]) and (X, Y) */
+static const long long PX4[8] = {0, 1, 2, 3, 8, 9, 10, 11}, PY4[8] = {4, 5, 6, 7, 12, 13, 14, 15};
+static const long long PX2[8] = {0, 1, 4, 5, 8, 9, 12, 13}, PY2[8] = {2, 3, 6, 7, 10, 11, 14, 15};
+static const long long PX1[8] = {0, 2, 4, 6, 8, 10, 12, 14}, PY1[8] = {1, 3, 5, 7, 9, 11, 13, 15};
+static const long long QA2[8] = {0, 1, 8, 9, 2, 3, 10, 11}, QB2[8] = {4, 5, 12, 13, 6, 7, 14, 15};
+static const long long QA1[8] = {0, 8, 1, 9, 2, 10, 3, 11}, QB1[8] = {4, 12, 5, 13, 6, 14, 7, 15};
+static const long long W4[8] = {0, 0, 0, 0, 1, 1, 1, 1}, W2[8] = {0, 0, 1, 1, 2, 2, 3, 3};
+/* the 16 / (2t) twiddles of a block spread over the 8 butterfly lanes */
+static inline v8 v_twiddles(const uint64_t* w, uint64_t t) {
+    if (t == 1) return VLD(w);
+    if (t == 2) return _mm512_permutexvar_epi64(VLD(W2), _mm512_castsi256_si512(_mm256_loadu_si256((const __m256i*)w)));
+    return _mm512_permutexvar_epi64(VLD(W4), _mm512_castsi128_si512(_mm_loadu_si128((const __m128i*)w)));
+}
+static inline __attribute__((always_inline)) void v_fwd_ntt(uint64_t* x, uint64_t n, const cb_mod* m, const int ifma) {
+    const v8 q = VSET(m->q), twoq = VSET(m->twoq);
+    uint64_t t = n >> 1;
+    for (uint64_t mm = 1; mm < n; mm <<= 1, t >>= 1) {
+        if (t >= 8) {
+            for (uint64_t i = 0; i < mm; i++) {
+                const v8 W = VSET(m->w[mm + i]), Wp = VSET(m->wp[mm + i]);
+                uint64_t *X = x + 2 * i * t, *Y = X + t;
+                for (uint64_t j = 0; j < t; j += 8) {
+                    const v8 tx = v_csub(VLD(X + j), twoq);
+                    const v8 Q = v_mul_shoup_lazy(VLD(Y + j), W, Wp, q, ifma);
+                    VST(X + j, _mm512_add_epi64(tx, Q));
+                    VST(Y + j, _mm512_sub_epi64(_mm512_add_epi64(tx, twoq), Q));
+                }
+            }
+        } else {
+            const v8 px = VLD(t == 4 ? PX4 : t == 2 ? PX2 : PX1), py = VLD(t == 4 ? PY4 : t == 2 ? PY2 : PY1);
+            const v8 qa = VLD(t == 4 ? PX4 : t == 2 ? QA2 : QA1), qb = VLD(t == 4 ? PY4 : t == 2 ? QB2 : QB1);
+            const uint64_t per = 8 / t;                                   /* twiddles per block of 16 */
+            for (uint64_t b = 0; b < n / 16; b++) {
+                const v8 A = VLD(x + 16 * b), B = VLD(x + 16 * b + 8);
+                const v8 W = v_twiddles(m->w + mm + per * b, t), Wp = v_twiddles(m->wp + mm + per * b, t);
+                const v8 tx = v_csub(_mm512_permutex2var_epi64(A, px, B), twoq);
+                const v8 Q = v_mul_shoup_lazy(_mm512_permutex2var_epi64(A, py, B), W, Wp, q, ifma);
+                const v8 Xn = _mm512_add_epi64(tx, Q), Yn = _mm512_sub_epi64(_mm512_add_epi64(tx, twoq), Q);
+                VST(x + 16 * b, _mm512_permutex2var_epi64(Xn, qa, Yn));
+                VST(x + 16 * b + 8, _mm512_permutex2var_epi64(Xn, qb, Yn));
+            }
+        }
+    }
+    for (uint64_t j = 0; j < n; j += 8) VST(x + j, v_csub(v_csub(VLD(x + j), twoq), q));
+}
+static inline __attribute__((always_inline)) void v_inv_ntt(uint64_t* x, uint64_t n, const cb_mod* m, const int ifma) {
+    const v8 q = VSET(m->q), twoq = VSET(m->twoq);
+    uint64_t t = 1, acc = 0;
+    for (uint64_t mm = n >> 1; mm >= 1; mm >>= 1, t <<= 1) {
+        if (t >= 8) {
+            for (uint64_t i = 0; i < mm; i++) {
+                const v8 W = VSET(m->iw[acc + i]), Wp = VSET(m->iwp[acc + i]);
+                uint64_t *X = x + 2 * i * t, *Y = X + t;
+                for (uint64_t j = 0; j < t; j += 8) {
+                    const v8 a = VLD(X + j), b = VLD(Y + j);
+                    VST(X + j, v_csub(_mm512_add_epi64(a, b), twoq));
+                    VST(Y + j, v_mul_shoup_lazy(_mm512_sub_epi64(_mm512_add_epi64(a, twoq), b), W, Wp, q, ifma));
+                }
+            }
+        } else {
+            const v8 px = VLD(t == 4 ? PX4 : t == 2 ? PX2 : PX1), py = VLD(t == 4 ? PY4 : t == 2 ? PY2 : PY1);
+            const v8 qa = VLD(t == 4 ? PX4 : t == 2 ? QA2 : QA1), qb = VLD(t == 4 ? PY4 : t == 2 ? QB2 : QB1);
+            const uint64_t per = 8 / t;
+            for (uint64_t b = 0; b < n / 16; b++) {
+                const v8 A = VLD(x + 16 * b), B = VLD(x + 16 * b + 8);
+                const v8 W = v_twiddles(m->iw + acc + per * b, t), Wp = v_twiddles(m->iwp + acc + per * b, t);
+                const v8 xa = _mm512_permutex2var_epi64(A, px, B), ya = _mm512_permutex2var_epi64(A, py, B);
+                const v8 Xn = v_csub(_mm512_add_epi64(xa, ya), twoq);
+                const v8 Yn = v_mul_shoup_lazy(_mm512_sub_epi64(_mm512_add_epi64(xa, twoq), ya), W, Wp, q, ifma);
+                VST(x + 16 * b, _mm512_permutex2var_epi64(Xn, qa, Yn));
+                VST(x + 16 * b + 8, _mm512_permutex2var_epi64(Xn, qb, Yn));
+            }
+        }
+        acc += mm;
+    }
+    const v8 in = VSET(m->inv_n), inp = VSET(m->inv_n_p);
+    for (uint64_t j = 0; j < n; j += 8) VST(x + j, v_csub(v_mul_shoup_lazy(VLD(x + j), in, inp, q, ifma), q));
+}
+/* x mod q for any x < 2^64, barr = floor(2^64 / q) (the mod-up / mod-down operands may exceed 52 bits: always the 64-bit form) */
+static inline v8 v_barrett1(v8 x, v8 barr, v8 q) {
+    return v_csub(_mm512_sub_epi64(x, _mm512_mullo_epi64(v_mulhi64(x, barr), q)), q);
+}
+#endif
+
+/* which kernels a modulus gets: HEXL's rule (IFMA below 2^50, 64-bit AVX512-DQ above), HEXL_CPU_ISA=scalar|dq to restrict */
+static int pick_isa(uint64_t q, uint64_t n) {
+    const char* e = getenv("HEXL_CPU_ISA");
+    if (e && !strcmp(e, "scalar")) return 0;
+    if (n < 16) return 0;
+#ifdef CB_AVX512
+    if (!__builtin_cpu_supports("avx512dq")) return 0;
+#ifdef CB_IFMA
+    if (q < (1ull << 50) && __builtin_cpu_supports("avx512ifma") && !(e && !strcmp(e, "dq"))) return 2;
+#endif
+    return 1;
+#else
+    (void)q;
+    return 0;
+#endif
+}
+static uint64_t shoup_for(uint64_t y, const cb_mod* m) {     /* floor(y 2^64 / q), or floor(y 2^52 / q) for the IFMA kernels */
+    return m->isa == 2 ? (uint64_t)(((u128)y << 52) / m->q) : orc_shoup_factor(y, m->q);
+}
+
 struct cb_plan* cb_plan_create(uint64_t n, uint64_t L, uint64_t K, const uint64_t* moduli, const uint64_t* const* keys,
                                const uint64_t* modswitch) {
     struct cb_plan* p = (struct cb_plan*)calloc(1, sizeof(*p));
@@ -93,14 +241,15 @@ struct cb_plan* cb_plan_create(uint64_t n, uint64_t L, uint64_t K, const uint64_
         cb_mod* m = &p->m[i];
         const uint64_t q = moduli[i];
         m->q = q; m->twoq = q << 1; m->barr_hi = (uint64_t)(((u128)1 << 64) / q);
+        m->isa = pick_isa(q, n);
         orc_tables_keyswitch(n, q, orc_minimal_primitive_root(2 * n, q), blk);     /* the oracle's (= reference's) tables */
         m->w = (uint64_t*)malloc(n * 8); m->wp = (uint64_t*)malloc(n * 8);
         m->iw = (uint64_t*)malloc(n * 8); m->iwp = (uint64_t*)malloc(n * 8);
         memcpy(m->iw, blk, n * 8);
         memcpy(m->w, blk + 2 * n, n * 8);
-        for (uint64_t j = 0; j < n; j++) { m->wp[j] = orc_shoup_factor(m->w[j], q); m->iwp[j] = orc_shoup_factor(m->iw[j], q); }
-        m->inv_n = orc_invmod(n, q); m->inv_n_p = orc_shoup_factor(m->inv_n, q);
-        m->msf = modswitch[i] % q; m->msf_p = orc_shoup_factor(m->msf, q);
+        for (uint64_t j = 0; j < n; j++) { m->wp[j] = shoup_for(m->w[j], m); m->iwp[j] = shoup_for(m->iw[j], m); }
+        m->inv_n = orc_invmod(n, q); m->inv_n_p = shoup_for(m->inv_n, m);
+        m->msf = modswitch[i] % q; m->msf_p = shoup_for(m->msf, m);
         m->half_mod = (q_sp >> 1) % q; m->fix = q - m->half_mod;
     }
     free(blk);
@@ -112,7 +261,7 @@ struct cb_plan* cb_plan_create(uint64_t n, uint64_t L, uint64_t K, const uint64_
                 const uint64_t i = slot < L ? slot : K - 1;
                 const uint64_t* key = keys[d] + (k * K + i) * n;
                 uint64_t* kp = p->key_p[d] + (k * (L + 1) + slot) * n;
-                for (uint64_t j = 0; j < n; j++) kp[j] = orc_shoup_factor(key[j] % p->m[i].q, p->m[i].q);
+                for (uint64_t j = 0; j < n; j++) kp[j] = shoup_for(key[j] % p->m[i].q, &p->m[i]);
             }
     }
     return p;
@@ -124,6 +273,74 @@ void cb_plan_destroy(struct cb_plan* p) {
     for (uint64_t d = 0; d < p->L; d++) free(p->key_p[d]);
     free(p->key_p); free(p->m); free(p);
 }
+
+
+static void fwd_ntt(uint64_t* x, uint64_t n, const cb_mod* m) {
+#ifdef CB_AVX512
+    if (m->isa == 2) { v_fwd_ntt(x, n, m, 1); return; }
+    if (m->isa == 1) { v_fwd_ntt(x, n, m, 0); return; }
+#endif
+    fwd_ntt_scalar(x, n, m);
+}
+static void inv_ntt(uint64_t* x, uint64_t n, const cb_mod* m) {
+#ifdef CB_AVX512
+    if (m->isa == 2) { v_inv_ntt(x, n, m, 1); return; }
+    if (m->isa == 1) { v_inv_ntt(x, n, m, 0); return; }
+#endif
+    inv_ntt_scalar(x, n, m);
+}
+/* the element-wise loops of cb_one, 8 lanes at a time when the modulus has vector kernels */
+static void mod_up_reduce(uint64_t* u, const uint64_t* src, uint64_t add, uint64_t n, const cb_mod* m) {      /* u = (src + add) mod q */
+#ifdef CB_AVX512
+    if (m->isa) {
+        const v8 q = VSET(m->q), barr = VSET(m->barr_hi), a = VSET(add);
+        for (uint64_t j = 0; j < n; j += 8) VST(u + j, v_barrett1(_mm512_add_epi64(VLD(src + j), a), barr, q));
+        return;
+    }
+#endif
+    for (uint64_t j = 0; j < n; j++) u[j] = barrett1(src[j] + add, m);
+}
+static inline __attribute__((always_inline)) void mac_keys_v(uint64_t* pr, const uint64_t* u, const uint64_t* key, const uint64_t* kp,
+                                                             uint64_t n, const cb_mod* m, const int ifma) {
+#ifdef CB_AVX512
+    const v8 q = VSET(m->q), twoq = VSET(m->twoq);
+    for (uint64_t j = 0; j < n; j += 8)
+        VST(pr + j, v_csub(_mm512_add_epi64(VLD(pr + j), v_mul_shoup_lazy(VLD(u + j), VLD(key + j), VLD(kp + j), q, ifma)), twoq));
+#else
+    (void)pr; (void)u; (void)key; (void)kp; (void)n; (void)m; (void)ifma;
+#endif
+}
+static void mac_keys(uint64_t* pr, const uint64_t* u, const uint64_t* key, const uint64_t* kp, uint64_t n, const cb_mod* m) {
+    if (m->isa == 2) { mac_keys_v(pr, u, key, kp, n, m, 1); return; }
+    if (m->isa == 1) { mac_keys_v(pr, u, key, kp, n, m, 0); return; }
+    for (uint64_t j = 0; j < n; j++)                                  /* lazy: prod < 2q throughout */
+        pr[j] = csub(pr[j] + mul_shoup_lazy(u[j], key[j], kp[j], m->q), m->twoq);
+}
+static inline __attribute__((always_inline)) void mod_down_v(uint64_t* res, const uint64_t* pr, const uint64_t* u, uint64_t n,
+                                                             const cb_mod* m, const int ifma) {
+#ifdef CB_AVX512
+    const v8 q = VSET(m->q), msf = VSET(m->msf), msfp = VSET(m->msf_p);
+    for (uint64_t j = 0; j < n; j += 8) {
+        const v8 in = _mm512_sub_epi64(_mm512_add_epi64(v_csub(VLD(pr + j), q), q), VLD(u + j));               /* < 2q */
+        const v8 out = v_csub(v_mul_shoup_lazy(in, msf, msfp, q, ifma), q);
+        VST(res + j, v_csub(_mm512_add_epi64(VLD(res + j), out), q));
+    }
+#else
+    (void)res; (void)pr; (void)u; (void)n; (void)m; (void)ifma;
+#endif
+}
+static void mod_down(uint64_t* res, const uint64_t* pr, const uint64_t* u, uint64_t n, const cb_mod* m) {
+    if (m->isa == 2) { mod_down_v(res, pr, u, n, m, 1); return; }
+    if (m->isa == 1) { mod_down_v(res, pr, u, n, m, 0); return; }
+    for (uint64_t j = 0; j < n; j++) {
+        const uint64_t in = csub(pr[j], m->q) + m->q - u[j];                 /* < 2q */
+        const uint64_t out = csub(mul_shoup_lazy(in, m->msf, m->msf_p, m->q), m->q);
+        res[j] = csub(res[j] + out, m->q);
+    }
+}
+
+/* which kernels the plan's first modulus uses: "scalar", "avx512dq", "avx512ifma" */
+const char* cb_isa(const struct cb_plan* p) { return p->m[0].isa == 2 ? "avx512ifma" : p->m[0].isa == 1 ? "avx512dq" : "scalar"; }
 
 /* one keyswitch, SURVEY 2.1-K4 steps 1-7, result accumulated into; `ws` = (L + 2(L+1) + 2) * n words of scratch */
 static void cb_one(const struct cb_plan* p, uint64_t* result, const uint64_t* t_target, uint64_t* ws) {
@@ -140,13 +357,11 @@ static void cb_one(const struct cb_plan* p, uint64_t* result, const uint64_t* t_
         for (uint64_t d = 0; d < L; d++) {
             const uint64_t* src = c + d * n;
             if (slot == d) memcpy(u, t_target + d * n, n * 8);       /* NTT(INTT(t_d) mod q_d) = t_d for in-range data */
-            else { for (uint64_t j = 0; j < n; j++) u[j] = barrett1(src[j], m); fwd_ntt(u, n, m); }
+            else { mod_up_reduce(u, src, 0, n, m); fwd_ntt(u, n, m); }
             for (uint64_t k = 0; k < 2; k++) {
                 const uint64_t* key = p->keys[d] + (k * K + i) * n;
                 const uint64_t* kp = p->key_p[d] + (k * (L + 1) + slot) * n;
-                uint64_t* pr = prod + (k * (L + 1) + slot) * n;
-                for (uint64_t j = 0; j < n; j++)                      /* lazy: prod < 2q throughout */
-                    pr[j] = csub(pr[j] + mul_shoup_lazy(u[j], key[j], kp[j], m->q), m->twoq);
+                mac_keys(prod + (k * (L + 1) + slot) * n, u, key, kp, n, m);
             }
         }
     }
@@ -158,15 +373,10 @@ static void cb_one(const struct cb_plan* p, uint64_t* result, const uint64_t* t_
         for (uint64_t j = 0; j < n; j++) s[j] = csub(s[j] + (msp->q >> 1), msp->q);
         for (uint64_t i = 0; i < L; i++) {
             const cb_mod* m = &p->m[i];
-            for (uint64_t j = 0; j < n; j++) u[j] = barrett1(s[j] + m->fix, m);
+            mod_up_reduce(u, s, m->fix, n, m);
             fwd_ntt(u, n, m);
             const uint64_t* pr = prod + (k * (L + 1) + i) * n;
-            uint64_t* res = result + (k * L + i) * n;
-            for (uint64_t j = 0; j < n; j++) {
-                const uint64_t in = csub(pr[j], m->q) + m->q - u[j];                 /* < 2q */
-                const uint64_t out = csub(mul_shoup_lazy(in, m->msf, m->msf_p, m->q), m->q);
-                res[j] = csub(res[j] + out, m->q);
-            }
+            mod_down(result + (k * L + i) * n, pr, u, n, m);
         }
     }
 }

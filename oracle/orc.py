@@ -168,6 +168,7 @@ def cpu_baseline_lib(march: str = "native") -> ctypes.CDLL:
         L.cb_ntt_fwd_batch.restype = ctypes.c_int
         L.cb_ntt_fwd_batch.argtypes = [ctypes.c_void_p, u64, P, u64, ctypes.c_int]
         L.cb_max_threads.restype = ctypes.c_int; L.cb_max_threads.argtypes = []
+        L.cb_isa.restype = ctypes.c_char_p; L.cb_isa.argtypes = [ctypes.c_void_p]
         _cb[march] = L
     return _cb[march]
 
@@ -188,6 +189,10 @@ class CpuKeySwitch:
         batch = ts.size // (self.L * self.n)
         assert results.size == batch * 2 * self.L * self.n
         return self.lib.cb_keyswitch_batch(self.h, p(results), p(ts), batch, threads)
+
+    def isa(self) -> str:
+        """kernels the plan's first modulus runs on: scalar / avx512dq / avx512ifma (HEXL's rule; HEXL_CPU_ISA restricts)"""
+        return self.lib.cb_isa(self.h).decode()
 
     def ntt_fwd_batch(self, x: np.ndarray, modulus_index: int = 0, threads: int = 0) -> int:
         return self.lib.cb_ntt_fwd_batch(self.h, modulus_index, p(x), x.size // self.n, threads)

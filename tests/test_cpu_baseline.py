@@ -31,3 +31,47 @@ def test_cpu_port_forward_ntt(orc):
     cb.close()
     t = orc.HexlTables(n, q)
     assert np.array_equal(got.reshape(4, n), orc.ntt_fwd(x, t))
+
+
+@pytest.mark.parametrize("restrict", ["", "dq", "scalar"])
+@pytest.mark.parametrize("bits,n,L,K", [(51, 16384, 3, 4), (48, 4096, 2, 3), (30, 1024, 2, 3)])
+def test_vector_kernels_equal_oracle(orc, monkeypatch, restrict, bits, n, L, K):
+    """the AVX-512 kernel families of the CPU baseline (IFMA with 52-bit Shoup factors below 2^50, 64-bit lanes above --
+    HEXL's selection rule) built for THIS host: every path returns the oracle's words. On a host without AVX-512 all three
+    runs take the scalar port (the assertion on isa() says which one ran)."""
+    if restrict:
+        monkeypatch.setenv("HEXL_CPU_ISA", restrict)
+    else:
+        monkeypatch.delenv("HEXL_CPU_ISA", raising=False)
+    case = KsCase(orc, n, L, K, seed=11, bits=bits)
+    cb = orc.CpuKeySwitch(n, L, K, case.moduli, case.keys, case.modswitch, march="native")
+    isa = cb.isa()
+    assert isa in ("scalar", "avx512dq", "avx512ifma")
+    if restrict == "scalar":
+        assert isa == "scalar"
+    if restrict == "dq":
+        assert isa != "avx512ifma"
+    if isa == "avx512ifma":
+        assert bits < 50
+    ts, rs = zip(*[case.inputs(orc, b) for b in range(2)])
+    got = np.concatenate(rs).copy()
+    cb.keyswitch_batch(got, np.concatenate(ts), 2)
+    cb.close()
+    assert np.array_equal(got, np.concatenate([case.expected(orc, t, r) for t, r in zip(ts, rs)])), isa
+
+
+def test_vector_kernels_on_a_mixed_prime_chain(orc):
+    """bridge-seal's chain 52,30,30,40,27,27,27 at a lower level (5 decomposition limbs of 7 key moduli): IFMA and 64-bit
+    kernels side by side in one plan, operands of the mod-up reductions wider than 52 bits' worth of the small moduli"""
+    from ks_util import primes_below
+    n, K, L = 2048, 7, 5
+    moduli = []
+    for bits in (52, 30, 30, 40, 27, 27, 27):
+        moduli.append(next(p for p in primes_below(orc, 8, 1 << bits, n) if p not in moduli))
+    case = KsCase(orc, n, L, K, seed=5, moduli=moduli)
+    cb = orc.CpuKeySwitch(n, L, K, case.moduli, case.keys, case.modswitch, march="native")
+    t, r = case.inputs(orc, 0)
+    got = r.copy()
+    cb.keyswitch_batch(got, t, 1)
+    cb.close()
+    assert np.array_equal(got, case.expected(orc, t, r))
