@@ -49,6 +49,7 @@ C_ABI = {
     "hexl_ks_plan_destroy": [_vp],
     "hexl_ks_set_keys": [_vp, ctypes.POINTER(_vp)],
     "hexl_keyswitch": [_vp, _vp, _vp, _sz],
+    "hexl_ks_range_check": [_vp],
     "hexl_multiply_relinearize": [_vp, _vp, _vp, _vp, _sz],
     "hexl_ks_scratch_bytes": [_vp, _sz],
     "hexl_ntt_fwd_host": [_vp, ctypes.POINTER(_vp), _sz, _vp, _vp, _u64, _u64],
@@ -192,6 +193,13 @@ class KeySwitchPlan:
 
     def keyswitch(self, result, t_target, batch: int):
         _check(lib().hexl_keyswitch(self.h, _ptr(result), _ptr(t_target), batch), "hexl_keyswitch")
+
+    def range_check(self) -> bool:
+        """True if every keyswitch since the last check saw in-range words (syncs the stream, clears the flag)"""
+        rc = lib().hexl_ks_range_check(self.h)
+        if rc not in (0, -4):
+            _check(rc, "hexl_ks_range_check")
+        return rc == 0
 
     def multiply_relinearize(self, out, a, b, batch: int):
         """out[batch][2][L][n] = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), one fused pass (N = 16384)"""

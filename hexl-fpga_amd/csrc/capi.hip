@@ -245,6 +245,10 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         HX_CHECK(hipMemcpy(p->d_mods_f64, fm.data(), K * sizeof(KsModF64), hipMemcpyHostToDevice));
         HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // input-range flag of the FP64 kernels (hexl_ks_range_check) + its pinned mirror; HEXL_KS_VALIDATE shares them
+    HX_CHECK(hipMalloc((void**)&p->d_flag, sizeof(u32)));
+    HX_CHECK(hipMemset(p->d_flag, 0, sizeof(u32)));
+    HX_CHECK(hipHostMalloc((void**)&p->h_flag, sizeof(u32), hipHostMallocDefault));
     HX_CHECK(hipMalloc((void**)&p->d_mods, K * sizeof(KsModulus)));
     HX_CHECK(hipMalloc((void**)&p->d_tables, tables.size() * sizeof(u64)));
     // integer-kernel keys (key words + Shoup factors): only plans that run the integer kernels hold them
@@ -336,6 +340,16 @@ extern "C" int hexl_keyswitch(hexl_ks_plan* p, uint64_t* d_result, const uint64_
     if (!p || !d_result || !d_t_target) return HEXL_E_BADARG;
     HX_CHECK(hipSetDevice(p->ctx->device));
     return hx_launch_keyswitch(p, d_result, d_t_target, batch, 7, nullptr);
+}
+
+extern "C" int hexl_ks_range_check(hexl_ks_plan* p) {
+    if (!p) return HEXL_E_BADARG;
+    hexl_ctx* c = p->ctx;
+    HX_CHECK(hipSetDevice(c->device));
+    HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), c->stream));
+    HX_CHECK(hipStreamSynchronize(c->stream));
+    return *p->h_flag ? HEXL_E_RANGE : 0;
 }
 
 extern "C" int hexl_multiply_relinearize(hexl_ks_plan* p, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b,
@@ -797,7 +811,7 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
     auto add_into = [&](u64* res, const u64* out) {
         for (size_t limb = 0; limb < 2 * L; ++limb) add_limb(res, out, limb);
     };
-    return run_pipeline(c, batch, sh, [](char*) {},
+    const int rc_pipe = run_pipeline(c, batch, sh, [](char*) {},
         [&](size_t first, size_t cnt, char* h) {
             if (cnt >= 4) parallel_for(cnt, [&](size_t b) { memcpy(h + b * tt, h_t_targets[first + b], tt); });
             else for (size_t b = 0; b < cnt; ++b) memcpy(h + b * tt, h_t_targets[first + b], tt);
@@ -816,4 +830,8 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
                 parallel_for(cnt * 2 * L, [&](size_t x) { add_limb(h_results[first + x / (2 * L)], (const u64*)(h + (x / (2 * L)) * rs), x % (2 * L)); });
             else for (size_t b = 0; b < cnt; ++b) add_into(h_results[first + b], (const u64*)(h + b * rs));
         });
+    if (rc_pipe) return rc_pipe;
+    // The FP64 kernels flag t_target words that are not below their modulus (the device-side result buffer starts at zero
+    // here, so `result` is the host's business). The pipeline has synchronised: the flag word comes with one more 4-byte copy.
+    return p->use_f64 ? hexl_ks_range_check(p) : 0;
 }

@@ -74,6 +74,22 @@ HX_HD uint64_t from_f64(double x) {
     return b & 0x000FFFFFFFFFFFFFull;
 }
 
+// The precondition of the FP64 kernels -- every input word below its modulus -- checked where the word is converted anyway:
+// one compare per word (NaN-safe form; words >= 2^53 convert inexactly but stay >= p), collected as a wave-uniform lane mask
+// (compare into a scalar register pair + scalar OR: no vector registers). The kernels OR the outcome into a per-plan flag
+// that hexl_ks_range_check() reads; results for out-of-range words are outside the contract either way.
+#if defined(__HIPCC__)
+typedef unsigned long long RangeMask;
+__device__ __forceinline__ double to_f64_checked(uint64_t x, const Mod m, RangeMask& out_of_range) {
+    const double d = to_f64(x);
+    out_of_range |= __builtin_amdgcn_ballot_w64(!(d < m.p));
+    return d;
+}
+__device__ __forceinline__ void report_range(RangeMask out_of_range, unsigned* flag) {
+    if (out_of_range != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+#endif
+
 // ---- butterflies (both outputs centred) ---------------------------------------------------------
 // Cooley-Tukey / forward (device/keyswitch/ntt_core.hpp:285-291):  X' = X + W*Y, Y' = X - W*Y.
 // The forward butterflies take the quotient from the product itself (mul_mod) instead of a second table of

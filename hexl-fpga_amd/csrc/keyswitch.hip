@@ -450,13 +450,13 @@ __global__ void k_ks_validate(const u64* __restrict__ t, const u64* __restrict__
 static int validate_inputs(hexl_ks_plan* p, const u64* d_result, const u64* d_t_target, size_t batch) {
     // one flag word per plan, allocated once, with a pinned host mirror (no hipMalloc / hipFree per call, nothing to leak on
     // an error path, no asynchronous copy into pageable memory)
-    if (!p->d_flag) {
-        HX_CHECK(hipMalloc((void**)&p->d_flag, sizeof(u32)));
-        HX_CHECK(hipHostMalloc((void**)&p->h_flag, sizeof(u32), hipHostMallocDefault));
-    }
+    // the plan's flag word and its pinned host mirror (allocated with the plan: nothing to allocate, free or leak per call, no
+    // asynchronous copy into pageable memory). It is shared with the kernels' own range flag: a violation found here is
+    // reported here and the flag left clean.
     HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), p->ctx->stream));
     hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, d_result, p->d_mods, p->L, p->n, batch, p->d_flag);
     HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
+    HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), p->ctx->stream));
     HX_CHECK(hipStreamSynchronize(p->ctx->stream));
     return *p->h_flag ? HEXL_E_RANGE : 0;
 }

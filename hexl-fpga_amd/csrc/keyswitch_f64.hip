@@ -26,6 +26,7 @@ struct KsArgsF {
     const u64* t_target;     // [chunk][L][n]
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
+    u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
 };
 
 __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswitch.hip: XCD-contiguous work ranges
@@ -46,8 +47,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     const double* tb = a.tables + size_t(d) * 4 * G::N;
     const u64* src = a.t_target + size_t(item) * G::N;
     double v[G::E];
+    hxf::RangeMask bad = 0;
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(src[G::idxB(r, tid)]), md.m);
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64_checked(src[G::idxB(r, tid)], md.m, bad), md.m);
+    hxf::report_range(bad, a.range_flag);
     // step 2 for slot == d needs no transform: NTT_{q_d}(INTT_{q_d}(t_d) mod q_d) = t_d (the reference recomputes
     // it; same value for in-range data). The registers already hold t_d in B order.
     {
@@ -119,8 +122,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
         const u64* src = a.t_target + size_t(item) * G::N;
         // uniform row pointer + unsigned 32-bit thread offset: SGPR-base addressing, no 64-bit VALU address math
         const u32 tB = u32(G::idxB(0, tid));
+        hxf::RangeMask bad = 0;
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) c[r] = hxf::reduce(hxf::to_f64((src + G::idxB(r, 0))[tB]), md.m);
+        for (int r = 0; r < G::E; ++r) c[r] = hxf::reduce(hxf::to_f64_checked((src + G::idxB(r, 0))[tB], md.m, bad), md.m);
+        hxf::report_range(bad, a.range_flag);
         // step 2 for slot == d needs no transform: NTT_{q_d}(INTT_{q_d}(t_d) mod q_d) = t_d (the reference
         // recomputes it; same value for in-range data). The registers already hold t_d in B order.
         double* ud = a.u + ((size_t(b) * (L + 1) + d) * L + d) * G::N;
@@ -255,11 +260,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     for (int r = 0; r < G::E; ++r) old[r] = (res + G::idxB(r, 0))[tB];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(pv[r] - v[r], md.msf, md.msf_p, m);    // ms.hpp:70-82
+    hxf::RangeMask bad = 0;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
-        const double rr = hxf::reduce(hxf::to_f64(old[r]) + v[r], m);                            // fpga.cpp:453-457
+        const double rr = hxf::reduce(hxf::to_f64_checked(old[r], m, bad) + v[r], m);            // fpga.cpp:453-457
         (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
     }
+    hxf::report_range(bad, a.range_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,6 +336,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.s = a.prod + p->cap * 2 * (L + 1) * n;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
+    a.range_flag = p->d_flag;
     // LAZY template argument = forward reduction period (f64_arith.hpp): 3 when every modulus <= 2^51(1+2^-7), 6 / 12
     // for moduli <= 2^50 / 2^49 (N = 16384 only; the smaller transforms keep 3), 0 = strict
     if (p->f64_lazy) {

@@ -76,6 +76,7 @@ struct KsArgsX {
     const u64* t_target;     // [chunk][L][n]
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
+    u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
     u32 key_stride;          // words between key[d][slot] rows: 2 n. (Profiling aid HEXL_KSX_KEY_ALIAS=1, WRONG RESULTS: 0, every key
                              // row reads row 0, which takes the key stream out of the L2-miss-side counters -- bench.py's DRAM-side estimate)
     // fused multiply + relinearize (hexl_multiply_relinearize): ciphertext pairs a, b [chunk][2][L][n]; the keyswitch input
@@ -129,14 +130,14 @@ __device__ __forceinline__ u32 xcd_item_x(u32 bid, u32 total) {   // XCD-contigu
 // register) and the A -> B exchange is a cross-wave re-deal through LDS.
 template <class G>
 __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* __restrict__ src, double* lds, int tid,
-                                                  const Mod m) {
+                                                  const Mod m, hxf::RangeMask& bad) {
     if constexpr (G::KL <= 2) {
         const u32 tB = u32(G::idxB(0, tid));
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64((src + G::idxB(r, 0))[tB]), m);
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64_checked((src + G::idxB(r, 0))[tB], m, bad), m);
     } else {
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64((src + G::idxA(r, 0))[u32(tid)]), m);
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64_checked((src + G::idxA(r, 0))[u32(tid)], m, bad), m);
         redeal_x<G, false, true>(v, lds, tid, [](int r, int t) { return G::idxA(r, t); },
                                  [](int r, int t) { return G::idxB(r, t); });
     }
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
         else return a.t_target + size_t(item) * G::N;
     };
     u64 raw[G::E];
+    hxf::RangeMask bad = 0;                                             // a t_target word >= its modulus (FP64 precondition)
     if constexpr (!FUSED && G::KL <= 2) {
         const u32 tB = u32(G::idxB(0, int(threadIdx.x)));
         const u64* p0 = src_of(wk.pos);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         } else if constexpr (G::KL <= 2) {
 #pragma unroll
-            for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(raw[r]), md.m);
+            for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64_checked(raw[r], md.m, bad), md.m);
             const u32 nitem = item + wk.step < wk.end ? item + wk.step : item;       // (last round: a harmless re-read)
             const u64* pn = src_of(nitem);
             const u32 tB = u32(G::idxB(0, tid));
@@ -296,13 +298,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
             };
             W::template inverse<false, decltype(request_next), (KX_IPRE != 0)>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, request_next);
         } else {
-            load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m);
+            load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m, bad);
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         }
         double* cd = a.c + size_t(item) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (cd + G::idxA(r, 0))[u32(tid)] = hxf::lift(v[r], md.m);
     }
+    hxf::report_range(bad, a.range_flag);
 }
 
 // steps 2-4 for the special slot of one instance: acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k], then
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 // (a0, a1, b0, b1 of this limb, natural order): k = 0: a0 b0; k = 1: a0 b1 + a1 b0; `res` is written, not accumulated into
 template <class G, class W, int FUSED_K = -1>
 __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
-                                               double* lds, int tid, const double* tb, const KsModF64& md,
+                                               double* lds, int tid, const double* tb, const KsModF64& md, hxf::RangeMask& bad,
                                                const u64* a0 = nullptr, const u64* a1 = nullptr, const u64* b0 = nullptr,
                                                const u64* b1 = nullptr) {
     const Mod m = md.m;
@@ -414,7 +417,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
             for (int r = 0; r < G::E / 2; ++r) old[r] = (res + G::idxB(r0 + r, 0))[tB];
 #pragma unroll
             for (int r = 0; r < G::E / 2; ++r) {
-                const double rr = hxf::reduce(hxf::to_f64(old[r]) + v[r0 + r], m);               // fpga.cpp:453-457
+                const double rr = hxf::reduce(hxf::to_f64_checked(old[r], m, bad) + v[r0 + r], m);   // fpga.cpp:453-457
                 (res + G::idxB(r0 + r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -431,7 +434,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     for (int r0 = 0; r0 < G::E; r0 += 8) {
 #pragma unroll
         for (int r = r0; r < r0 + 8; ++r)
-            atA[G::pad(G::idxA(r, 0))] = hxf::reduce(hxf::to_f64((res + G::idxA(r, 0))[u32(tid)]), m);
+            atA[G::pad(G::idxA(r, 0))] = hxf::reduce(hxf::to_f64_checked((res + G::idxA(r, 0))[u32(tid)], m, bad), m);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -492,7 +495,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
                 const size_t at = ((size_t(b) * 2 + 1) * L + i) * G::N;
                 load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, m);
             } else {
-                load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m);
+                hxf::RangeMask ignore = 0;                              // (k_ksx_intt has checked this limb)
+                load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m, ignore);
             }
             KX_STAMP(61);
             mac_keys<G>(acc0, acc1, v, k0, round_src(first), tid, m);
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
     }
     // rounds L, L+1 (k = 0, 1)
+    hxf::RangeMask bad = 0;                                             // a result word >= its modulus (FP64 precondition)
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -531,8 +536,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* tb = a.tables + toff;
         KX_STAMP(4 * L + 0);
         const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * G::N;
-        if constexpr (FUSED) ksx_down_round<G, W, 0>(v, acc0, a.result + o0, ldsx, tid, tb, md, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W>(v, acc0, a.result + o0, ldsx, tid, tb, md);
+        if constexpr (FUSED) ksx_down_round<G, W, 0>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
+        else ksx_down_round<G, W>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
         const double* nxt = a.s + (size_t(b) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -545,9 +550,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * G::N;
-        if constexpr (FUSED) ksx_down_round<G, W, 1>(v, acc1, a.result + o1, ldsx, tid, tb, md, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W>(v, acc1, a.result + o1, ldsx, tid, tb, md);
+        if constexpr (FUSED) ksx_down_round<G, W, 1>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
+        else ksx_down_round<G, W>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
         KX_STAMP(4 * L + 8);
+        hxf::report_range(bad, a.range_flag);
     }
     }
 }
@@ -631,6 +637,7 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.stamps = nullptr;
     static const u32 alias = [] { const char* e = getenv("HEXL_KSX_KEY_ALIAS"); return (e && atoi(e) == 1) ? 1u : 0u; }();
     a.key_stride = alias ? 0u : u32(2 * n);
+    a.range_flag = p->d_flag;
     switch (p->logn) {
         case 10: return launch_x_small<10>(p, a, stage_mask, ev);
         case 11: return launch_x_small<11>(p, a, stage_mask, ev);
@@ -663,6 +670,7 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
     a.mul_a = d_a; a.mul_b = d_b;
     a.stamps = nullptr;
     a.key_stride = u32(2 * n);
+    a.range_flag = p->d_flag;
     // (moduli small enough for the longer lazy periods run with period 3 here: always valid, two fewer kernel variants)
     return p->f64_lazy ? run_chunk_x<14, 4, 3, true>(p, a, 7, nullptr) : run_chunk_x<14, 4, 0, true>(p, a, 7, nullptr);
 }

@@ -209,6 +209,16 @@ void execute(Engine& e, Device& dev, const std::vector<Obj>& run) {
         }
         default: break;
     }
+    if (rc == HEXL_E_RANGE && f.kind == KS) {
+        // a t_target word not below its modulus: outside intel::hexl::KeySwitch's contract (the reference checks nothing and
+        // returns whatever its pipeline makes of it). Like an FPGA_ASSERT (fpga_assert.h:24-38) this is fatal only under
+        // FPGA_DEBUG; otherwise say so once and carry on.
+        if (e.debug) die("KeySwitch: a t_target word is not below its modulus", rc);
+        static bool said = false;
+        if (!said) std::fprintf(stderr, "[hexl-fpga/mi355x] warning: KeySwitch got a t_target word >= its modulus; the result of that object is unspecified\n");
+        said = true;
+        return;
+    }
     if (rc) die(kind_name[f.kind], rc);
 }
 

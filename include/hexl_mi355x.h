@@ -27,7 +27,7 @@ extern "C" {
 #define HEXL_E_BADARG   (-1)   /* unsupported n / null pointer / size limit */
 #define HEXL_E_NOKEYS   (-2)   /* hexl_keyswitch before hexl_ks_set_keys */
 #define HEXL_E_NODEVICE (-3)   /* no gfx950 device visible */
-#define HEXL_E_RANGE    (-4)   /* HEXL_KS_VALIDATE=1: a t_target / result word is not below its modulus */
+#define HEXL_E_RANGE    (-4)   /* a t_target / result word is not below its modulus (hexl_ks_range_check, HEXL_KS_VALIDATE=1) */
 
 typedef struct hexl_ctx hexl_ctx;         /* one per GPU: stream + scratch */
 typedef struct hexl_ks_plan hexl_ks_plan; /* keyswitch parameter set: tables + keys on device */
@@ -99,6 +99,13 @@ int hexl_ks_set_keys(hexl_ks_plan* plan, const uint64_t* const* h_keys);
  * device/keyswitch/ (SURVEY 2.1-K4). */
 int hexl_keyswitch(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_target,
                    size_t batch);
+/* The FP64 kernels (moduli < 2^52) check the precondition above where they convert the words anyway -- one compare per
+ * word, no extra pass -- and OR the outcome into a flag of the plan. This call waits for the plan's stream and returns
+ * HEXL_E_RANGE if any hexl_keyswitch launched on the plan since the previous check saw a t_target / result word >= its
+ * modulus (their output words for that instance are then unspecified), 0 otherwise; it clears the flag. The integer kernels
+ * (moduli >= 2^52) do not flag: they replay the reference's lazy arithmetic on whatever words they get.
+ * hexl_keyswitch_host() calls it itself and returns its status. */
+int hexl_ks_range_check(hexl_ks_plan* plan);
 /* Beyond the reference's envelope (the use-case of its combined image,
  * device/dyadic_multiply_keyswitch.cpp:4-5): ciphertext multiply + relinearize in one pass.
  *   d_a, d_b [batch][2][L][n] (the DyadicMultiply operand layout with n_moduli = L, words < q_i);

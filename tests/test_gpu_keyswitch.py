@@ -317,6 +317,38 @@ except hx.HexlError as e:
     assert out.returncode == 0 and "REJECTED True True" in out.stdout
 
 
+@pytest.mark.parametrize("nb", [1, 96, 600])
+def test_range_flag_of_the_fp64_kernels(hx, ctx, dev, orc, nb):
+    """the FP64 kernels check their precondition (every word below its modulus) where they convert the words: a single
+    out-of-range word anywhere in a batch -- in t_target or in result, on the (b, d)-major pipeline (1 instance), the slot-major
+    one (96) and across scratch chunks (600) -- shows up in hexl_ks_range_check; clean batches report clean and match the oracle"""
+    import torch
+    n, L, K = 16384, 3, 4
+    case = KsCase(orc, n, L, K, seed=12)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    t, r = case.inputs(orc, 0)
+    d_t = hx.as_i64(np.tile(t, nb)).to(dev)
+    d_r = hx.as_i64(np.tile(r, nb)).to(dev)
+    plan.keyswitch(d_r, d_t, nb)
+    assert plan.range_check() is True
+    out = hx.to_u64(d_r).reshape(nb, -1)
+    want = case.expected(orc, t, r)
+    assert np.array_equal(out[0], want) and np.array_equal(out[nb - 1], want)
+    for where in ("t", "r"):
+        d_t = hx.as_i64(np.tile(t, nb)).to(dev)
+        d_r = hx.as_i64(np.tile(r, nb)).to(dev)
+        b = nb - 1 if nb > 1 else 0
+        if where == "t":                                         # instance b, limb 2, coefficient 77: exactly q
+            d_t[b * L * n + 2 * n + 77] = int(case.moduli[2])
+        else:                                                     # component 1, limb 0: 2^63 (converts inexactly, still >= q)
+            d_r[b * 2 * L * n + (1 * L + 0) * n + 5] = -(1 << 63)
+        plan.keyswitch(d_r, d_t, nb)
+        assert plan.range_check() is False, where
+        assert plan.range_check() is True                         # the check clears the flag
+    plan.close()
+
+
 @pytest.mark.parametrize("env", [{"HEXL_KS_PIPE": "1"}, {"HEXL_KSX_LOGE": "5", "HEXL_KS_PIPE": "3"}, {"HEXL_KSX_PERSIST": "0"},
                                  {"HEXL_KS_ONE_LANE": "1"}, {"HEXL_KS_INT": "1"}, {"HEXL_KS_INT": "1", "HEXL_KS_PIPE": "1"},
                                  {"HEXL_KS_INT": "1", "HEXL_KSI_LOGE": "4"},

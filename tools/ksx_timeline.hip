@@ -42,6 +42,8 @@ int main(int argc, char** argv) {
     for (auto& x : t) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; x = (seed >> 13) % (u64)p0; }
     for (auto& x : res) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; x = (seed >> 13) % (u64)p0; }
 
+    u32* dflag = nullptr;
+    hipMalloc((void**)&dflag, 4); hipMemset(dflag, 0, 4);
     KsArgsX a;
     KsModF64* dm; double *dt, *dk, *dc, *ds; u64 *dtt, *dres; unsigned long long* dst;
     hipMalloc(&dm, K * sizeof(KsModF64)); hipMalloc(&dt, tables.size() * 8); hipMalloc(&dk, keys.size() * 8);
@@ -55,7 +57,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dtt, t.data(), t.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dres, res.data(), res.size() * 8, hipMemcpyHostToDevice);
     a.mods = dm; a.tables = dt; a.keys = dk; a.c = dc; a.s = ds; a.t_target = dtt; a.result = dres;
-    a.L = L; a.K = K; a.nb = nb; a.stamps = dst; a.key_stride = 2u << 14;
+    a.L = L; a.K = K; a.nb = nb; a.stamps = dst; a.key_stride = 2u << 14; a.range_flag = dflag;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto kin = k_ksx_intt<14, KX_LOGE, 3>;
     hipFuncSetAttribute((const void*)kin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
