@@ -167,3 +167,62 @@ def test_keyswitch_golden_digests(orc):
         e = case.expected(orc, t, r)
         assert f"{orc.fnv(e):016x}" == v["fnv_result_out"], v
         assert [int(e[0]), int(e[len(e) // 2]), int(e[-1])] == v["out_first_mid_last"]
+
+
+@pytest.mark.parametrize("L,K", [(6, 7), (7, 8)])
+def test_baseline_shape_against_a_coefficient_domain_model(orc, L, K):
+    """A third, independent cross-check AT THE BASELINE SHAPE (N = 16384, 51-bit primes; the O(n^2) models above stop at
+    n = 1024): the key multiply-accumulate, the mod-up reduction, the special-prime rounding and the mod-down are redone in
+    the COEFFICIENT domain with Python integers -- a keyswitch output limb is NTT_i of R(X) = (P_i(X) - t(X)) / q_sp with
+    P_i = sum_d (c_d mod q_i) * K_{d,i} (negacyclic product), t = the centred remainder of P_sp modulo q_sp -- on 48 sampled
+    coefficients of every output limb. Only the transforms themselves (c_d = INTT(t_d), K = INTT(key), the final INTT of the
+    output) are the oracle's, and those are pinned to the reference's own code (tests/test_oracle_golden.py)."""
+    n = 16384
+    case = KsCase(orc, n, L, K, seed=21)
+    qs = [int(v) for v in case.moduli]
+    sp, q_sp = K - 1, int(case.moduli[K - 1])
+    half = q_sp >> 1
+    t, r = case.inputs(orc, 0)
+    out = case.expected(orc, t, r)
+    blks = []
+    for q in qs:
+        b = np.zeros(4 * n, dtype=np.uint64)
+        orc.orc().orc_tables_keyswitch(n, q, orc.orc().orc_minimal_primitive_root(2 * n, q), orc.p(b))
+        blks.append(b)
+
+    def intt(x, i):
+        y = np.ascontiguousarray(x, dtype=np.uint64).copy()
+        orc.orc().orc_ks_intt(orc.p(y), n, qs[i], orc.p(blks[i][0:n]))
+        return y
+
+    c = [intt(t[d * n:(d + 1) * n], d).astype(object) for d in range(L)]                     # step 1, coefficient domain
+    rng = np.random.default_rng(3)
+    sample = sorted(set([0, 1, n - 1] + [int(v) for v in rng.integers(0, n, 45)]))
+    idx = np.arange(n)
+
+    def conv_at(a, b, j, q):
+        """coefficient j of a * b mod (X^n + 1, q): sum_{x + y = j} a_x b_y - sum_{x + y = j + n} a_x b_y"""
+        y = (j - idx) % n
+        sign = np.where(idx <= j, 1, -1).astype(object)
+        return int(np.dot(a * sign, b[y])) % q
+
+    # per slot: key polynomials in the coefficient domain, the mod-up of c_d, and the sampled products
+    def slot_products(i, k):
+        acc = {j: 0 for j in sample}
+        for d in range(L):
+            kc = intt(case.keys[d][(k * K + i) * n:(k * K + i + 1) * n], i).astype(object)
+            cd = c[d] % qs[i]                                                                # intt1_redu.hpp:36-42
+            for j in sample:
+                acc[j] = (acc[j] + conv_at(cd, kc, j, qs[i])) % qs[i]
+        return acc
+
+    for k in range(2):
+        S = slot_products(sp, k)
+        tc = {j: ((S[j] + half) % q_sp) - half for j in sample}                              # intt2_redu.hpp:25,43,49-51
+        for i in range(L):
+            P = slot_products(i, k)
+            inv = pow(q_sp, -1, qs[i])
+            delta = (out[(k * L + i) * n:(k * L + i + 1) * n].astype(object) - r[(k * L + i) * n:(k * L + i + 1) * n].astype(object)) % qs[i]
+            got = intt(np.array(delta, dtype=np.uint64), i)
+            for j in sample:
+                assert int(got[j]) == (P[j] - tc[j]) * inv % qs[i], (k, i, j)                # ms.hpp:70-82
