@@ -657,10 +657,19 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     }
 }
 
-// fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry)
+// fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry).
+// Ring dimensions whose partial pass leaves a lane at most four adjacent words (N = 1024, 8192, 16384): the operand limbs are
+// read straight at the transforms' B positions. (N = 2048 / 4096 would need the LDS re-deal of load_natural_to_B for five
+// operand streams; N = 32768 has no slot-major pipeline at all -- 64 registers of polynomial + 128 of accumulators do not fit
+// a 1024-thread workgroup.)
+template <int LOGN>
+static int mulrelin_for(hexl_ks_plan* p, const KsArgsX& a) {
+    // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
+    return p->f64_lazy ? run_chunk_x<LOGN, 4, 3, true>(p, a, 7, nullptr) : run_chunk_x<LOGN, 4, 0, true>(p, a, 7, nullptr);
+}
 int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t nb) {
     const size_t n = p->n, L = p->L;
-    if (p->logn != 14 || !p->use_f64 || !p->d_keys_x || p->x_loge != 4) return HEXL_E_BADARG;
+    if (!p->use_f64 || !p->d_keys_x || p->x_loge != 4) return HEXL_E_BADARG;
     KsArgsX a;
     a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_x;
     a.c = (double*)p->cur_scratch;
@@ -671,6 +680,10 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
     a.stamps = nullptr;
     a.key_stride = u32(2 * n);
     a.range_flag = p->d_flag;
-    // (moduli small enough for the longer lazy periods run with period 3 here: always valid, two fewer kernel variants)
-    return p->f64_lazy ? run_chunk_x<14, 4, 3, true>(p, a, 7, nullptr) : run_chunk_x<14, 4, 0, true>(p, a, 7, nullptr);
+    switch (p->logn) {
+        case 10: return mulrelin_for<10>(p, a);
+        case 13: return mulrelin_for<13>(p, a);
+        case 14: return mulrelin_for<14>(p, a);
+        default: return HEXL_E_BADARG;
+    }
 }

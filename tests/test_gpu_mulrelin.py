@@ -25,9 +25,9 @@ def composed(orc, case, a, b):
     return out
 
 
-@pytest.mark.parametrize("L,K,nb,strict", [(6, 7, 2, False), (7, 8, 96, False), (3, 4, 5, True)])
-def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, L, K, nb, strict):
-    n = 16384
+@pytest.mark.parametrize("n,L,K,nb,strict", [(16384, 6, 7, 2, False), (16384, 7, 8, 96, False), (16384, 3, 4, 5, True),
+                                             (8192, 3, 4, 70, False), (1024, 2, 3, 300, False), (8192, 2, 3, 3, True)])
+def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, n, L, K, nb, strict):
     moduli = primes_below(orc, K, 1 << 52, n) if strict else None      # just below 2^52: the strict FP64 kernels
     case = KsCase(orc, n, L, K, seed=40 + L, moduli=moduli)
     plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
