@@ -9,12 +9,13 @@ mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/kt $OUT/pmc
 # one lane: the default schedule alternates chunks between two streams, whose kernels then overlap and stretch each
 # other's durations in the trace; one lane gives per-kernel durations that add up (bench.py's stage timers are one-lane too)
-HEXL_KS_ONE_LANE=1 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu > $OUT/bench_under_trace.log 2>&1
+HEXL_KS_ONE_LANE=1 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu --no-pmc > $OUT/bench_under_trace.log 2>&1
 python3 $R/tools/rocprof_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_trace.txt 2>&1
 python3 $R/tools/overlap.py $(find $OUT/kt -name "*.db" | head -1) >> $OUT/kernel_trace.txt 2>&1
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_IFETCH" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_VMEM" \
            "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   # one lane: every dispatch is one whole chunk of 256 keyswitches, so per-dispatch averages divide by 256
@@ -24,5 +25,5 @@ python3 $R/tools/pmc_summary.py $OUT/pmc 256 7 > $OUT/pmc.txt 2>&1
 cp $OUT/pmc/traffic.json $OUT/traffic.json 2>/dev/null
 cp $OUT/pmc/alu.json $OUT/alu.json 2>/dev/null
 rm -rf $OUT/pmc $OUT/kt
-python $R/bench.py 2>/dev/null | tail -1 > $OUT/bench.json
+python $R/bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 tail -3 $OUT/pmc.txt
