@@ -194,3 +194,45 @@ def test_out_of_range_polynomials_inside_a_persistent_batch(hx, ctx, dev, orc, n
         want = (orc.ntt_fwd if fwd else orc.ntt_inv)(x[sample], t)
         assert np.array_equal(got[sample], want)
         distinct[fwd] = got
+
+
+@pytest.mark.parametrize("n,batch", [(16384, 1024), (4096, 3000)])
+def test_tables_edited_in_place_between_calls(hx, ctx, dev, orc, n, batch):
+    """nothing about the caller's tables may be remembered across calls unless it is re-verified: the same table tensors are
+    (1) reused over several calls, (2) edited IN PLACE by one word between calls (same pointers; the reference's answer for
+    improper tables is the integer butterflies on exactly those words), (3) restored -- every call must match the oracle for
+    the tables as they are AT THAT CALL; forward and inverse tables alternate, as in bench.py. (Written for a table cache whose
+    kernels re-hash the tables -- tools/experiments/ntt_table_cache.patch, sound but no faster -- and kept as the guard for any
+    future one.)"""
+    import torch
+    q = orc.primes(1, 51, n)[0]
+    t = orc.HexlTables(n, q)
+    base = np.stack([orc.splitmix(n, 70 + b, q) for b in range(3)])
+    x = base[np.arange(batch) % 3].copy()
+    tabs = [_dev(hx, a, dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
+
+    def check(edit=None):
+        tt = t
+        if edit is not None:                                     # the oracle with the same word flipped
+            import copy
+            tt = copy.copy(t)
+            tt.roots = t.roots.copy(); tt.inv_roots = t.inv_roots.copy()
+            tt.roots[edit] ^= np.uint64(1); tt.inv_roots[edit] ^= np.uint64(1)
+        for fwd in (True, False):
+            d = _dev(hx, x, dev)
+            if fwd:
+                ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)
+            else:
+                ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
+            ctx.sync()
+            got = hx.to_u64(d).reshape(batch, n)
+            want = (orc.ntt_fwd if fwd else orc.ntt_inv)(base, tt)
+            assert np.array_equal(got[:3], want) and np.array_equal(got[batch - 3:], want[(np.arange(batch - 3, batch)) % 3]), (fwd, edit)
+
+    check(); check(); check()                                    # miss, then hits
+    for pos in (5, n - 1):
+        one = torch.tensor(1, dtype=torch.int64, device=dev)
+        tabs[0][pos] ^= one; tabs[2][pos] ^= one                 # in place, same pointers
+        check(edit=pos); check(edit=pos)                         # stale cache detected by the kernel, then verified again
+        tabs[0][pos] ^= one; tabs[2][pos] ^= one
+        check(); check()
