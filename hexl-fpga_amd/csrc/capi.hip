@@ -407,7 +407,9 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 static unsigned host_threads() {                                   // (thread-safe static: several device runners call this)
     static const unsigned n = [] {
         const char* e = getenv("HEXL_HOST_THREADS");
-        const unsigned v = e ? (unsigned)atoi(e) : std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        // 8: swept on the 256-thread boxes of this pool (tools/r3_run_k.sh): 2 / 4 / 8 / 12 / 32 / 64 copy threads move 12 / 21 / 26 / 27 /
+        // 19 / 12 k keyswitch/s through the host-pointer API at worksize 1024 -- the copies are memory-bound, more threads only contend
+        const unsigned v = e ? (unsigned)atoi(e) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
         return v ? v : 1u;
     }();
     return n;
@@ -634,9 +636,9 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     return rc;
 }
 
-static size_t sub_batch_for(size_t bytes_per_item) {              // ~32 MB slabs keep all stages busy
+static size_t sub_batch_for(size_t bytes_per_item) {              // ~128 MB slabs (32 MB measured 15-25 % slower at worksize 1024)
     const char* e = getenv("HEXL_HOST_SUB_MB");
-    const size_t target = (e ? (size_t)atoi(e) : 32) << 20;
+    const size_t target = (e ? (size_t)atoi(e) : 128) << 20;
     return std::max<size_t>(1, target / std::max<size_t>(1, bytes_per_item));
 }
 
