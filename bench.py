@@ -170,6 +170,65 @@ def cpu_baseline(orc_mod, case, budget_s=10.0):
                       f"{int(case.moduli[0]).bit_length()}-bit), gcc -O3 -march=native -fopenmp; Intel HEXL itself is not in the image"}
 
 
+class PowerSampler:
+    """Board power and shader clock from the amdgpu hwmon files of the benchmarked GPU, sampled every 50 ms on a thread while
+    the timed region runs. Every kernel family of this library runs the board AT its power cap (1378-1400 W of
+    1400 W), so the shader clock in `roofline.alu` is what power management leaves, not a constant of the chip."""
+
+    def __init__(self, torch_device_index):
+        import glob
+        self.dir = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            hits = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hits:
+                self.dir = hits[0]
+        except Exception:
+            pass
+        if self.dir is None:
+            for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+                if os.path.exists(d + "/power1_average") or os.path.exists(d + "/power1_input"):
+                    self.dir = d
+                    break
+        self.samples, self._stop, self._th = [], False, None
+
+    def _read(self, name):
+        try:
+            return float(open(f"{self.dir}/{name}").read())
+        except Exception:
+            return None
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+
+        def loop():
+            while not self._stop:
+                w = self._read("power1_average") or self._read("power1_input")
+                f = self._read("freq1_input")
+                if w:
+                    self.samples.append((w / 1e6, f / 1e6 if f else None))
+                time.sleep(0.05)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th:
+            self._th.join()
+        if not self.samples:
+            return None
+        ws = [w for w, _ in self.samples]
+        fs = [f for _, f in self.samples if f]
+        cap = self._read("power1_cap")
+        return {"samples": len(ws), "board_power_w_mean": sum(ws) / len(ws), "board_power_w_max": max(ws),
+                "power_cap_w": cap / 1e6 if cap else None, "sclk_mhz_mean": sum(fs) / len(fs) if fs else None,
+                "source": self.dir}
+
+
 def ctx_cus(ctx):
     import re
     m = re.search(r"(\d+) CUs", ctx.describe())
@@ -307,6 +366,9 @@ def main():
     for _ in range(a.warmup):
         plan.keyswitch(d_r, d_t, mine)
     barrier()
+    power = PowerSampler(local) if rank == 0 else None
+    if power:
+        power.start()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -317,6 +379,7 @@ def main():
     e1.record()
     barrier()
     elapsed = slowest(time.perf_counter() - t0)
+    power = power.stop() if power else None
     dev_ms = e0.elapsed_time(e1)                              # HIP events on the launch stream
 
     value = total * a.steps / elapsed
@@ -393,7 +456,9 @@ def main():
                                                "ms_per_chunk": stage[3], "share_of_pipeline": stage[3] / stage[0],
                                                "chunk": min(mine, 256)},
                            # the binding bound: 72 N-point transforms of exact 52-bit arithmetic per 4.6 MB
-                           "alu": alu}
+                           "alu": alu,
+                           # ... and what sets the clock in it: the board's power cap (hwmon samples over the timed region)
+                           "power": power}
         extra = {"stage_ms_at_batch_%d" % min(mine, 256): {"total": stage[0], "step_1_inverse_transforms": stage[1],
                                                              "steps_2_4_special_limb": stage[2],
                                                              "steps_2_3_5_7_decomposition_limbs": stage[3]},

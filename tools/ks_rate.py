@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """keyswitch/s of the current library under the caller's environment (HEXL_KS_INT, HEXL_KS_PIPE, HEXL_KSI_LOGE, ...),
-after checking three instances against the oracle. usage: ks_rate.py [batch] [decomp] [bits] [reps]"""
+after checking three instances against the oracle. usage: ks_rate.py [batch] [decomp] [bits] [reps] [n]"""
 import sys
 import time
 from pathlib import Path
@@ -18,7 +18,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 bits = int(sys.argv[3]) if len(sys.argv) > 3 else 51
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-n = 16384
+n = int(sys.argv[5]) if len(sys.argv) > 5 else 16384
 dev = torch.device("cuda:0")
 ctx = hx.Context(0)
 case = KsCase(orc, n, L, L + 1, seed=1, bits=bits)
