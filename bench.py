@@ -16,7 +16,8 @@ Default = BASELINE config 5 as stated: ONE batch of 8192 ciphertexts per step sp
 step is 5 ms: tests/test_gpu_bench_ranks.py).
 
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (its `traffic` and `alu` inputs are PMC passes
-of tools/pmc_workload run INSIDE this benchmark at N = 1; --no-pmc falls back to profiles/*_latest.json), `cpu_baseline`
+of tools/pmc_workload run INSIDE this benchmark at N = 1; --no-pmc falls back to profiles/*_latest.json; `roofline.power` =
+board power and shader clock sampled from hwmon over the timed region), `cpu_baseline`
 and `extra` (fwd/inv NTT rates over ALL ranks -- BASELINE's second metric --, per-stage kernel times, the
 reference-representable L=6/K=7 shape).
 """
