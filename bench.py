@@ -397,7 +397,8 @@ def main():
                    "parallelism": f"{world} independent shard(s), no collective"},
     }
     # BASELINE's second metric, fwd-NTT/sec at N=16384 at 1/2/4/8 GPUs: config 2's shape on every rank, whole-job rate
-    ntt = None if a.no_extra else time_ntt(hx, ctx, orc_mod, dev, 1024, 10, barrier, slowest, world)
+    # (300 launches per leg, ~25 ms: ten launches end before the clocks and the power limit have settled and read 8 % low)
+    ntt = None if a.no_extra else time_ntt(hx, ctx, orc_mod, dev, 1024, 300, barrier, slowest, world)
     if rank == 0:
         alg = ks_alg_bytes(N, L)
         ach = alg * mine * a.steps / (dev_ms * 1e-3) / 1e9            # this rank, device-timed
