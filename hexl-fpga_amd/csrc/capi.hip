@@ -819,8 +819,13 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
             else for (size_t b = 0; b < cnt; ++b) memcpy(h + b * tt, h_t_targets[first + b], tt);
         },
         [&](size_t cnt, char* d, char* dout) {
-            HX_CHECK(hipMemsetAsync(dout, 0, cnt * rs, c->stream));
-            return hexl_keyswitch(p, (u64*)dout, (u64*)d, cnt);
+            // small sub-batches run on kernels that can WRITE their output: no zeroed buffer to prepare and to read back
+            const bool ow = hx_ks_can_overwrite(p, cnt);
+            if (!ow) HX_CHECK(hipMemsetAsync(dout, 0, cnt * rs, c->stream));
+            p->overwrite_result = ow;
+            const int rc = hexl_keyswitch(p, (u64*)dout, (u64*)d, cnt);
+            p->overwrite_result = false;
+            return rc;
         },
         [&](size_t first, size_t cnt, const char* h) {
             bool distinct = true;                                   // aliased results must be added in order

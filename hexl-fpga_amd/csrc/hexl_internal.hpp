@@ -111,6 +111,7 @@ struct hexl_ks_plan {
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     u32* d_flag = nullptr;            // one device word + its pinned host mirror: input-range flag (HEXL_KS_VALIDATE)
     u32* h_flag = nullptr;
+    bool overwrite_result = false;    // host-pointer path, (b, d)-major FP64 kernels: write `result` instead of accumulating into it
     hipStream_t cur = nullptr;        // stream the chunk being launched goes to
     u64* cur_scratch = nullptr;
 };
@@ -130,6 +131,8 @@ int hx_launch_keyswitch_f64(hexl_ks_plan*, u64* d_result, const u64* d_t_target,
 int hx_launch_keyswitch_x(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
                           hipEvent_t* ev);
 bool hx_ks_x_applies(const hexl_ks_plan*, size_t nb);
+// true when a batch of nb runs entirely on kernels that honour hexl_ks_plan::overwrite_result
+bool hx_ks_can_overwrite(const hexl_ks_plan*, size_t nb);
 int hx_launch_multiply_relinearize(hexl_ks_plan*, u64* d_out, const u64* d_a, const u64* d_b, size_t batch);
 u32 hx_ks_x_loge();
 // index of coefficient held in register r of thread tid after a forward transform ("B layout")

@@ -461,6 +461,13 @@ static int validate_inputs(hexl_ks_plan* p, const u64* d_result, const u64* d_t_
     return *p->h_flag ? HEXL_E_RANGE : 0;
 }
 
+// the (b, d)-major FP64 kernels can write `result` instead of accumulating into it: every chunk of the batch must take them
+bool hx_ks_can_overwrite(const hexl_ks_plan* p, size_t nb) {
+    if (!p->use_f64 || p->logn > 14) return false;               // (N = 32768: no registers for a second epilogue)
+    const size_t chunk = nb < ks_chunk_default(p) ? nb : ks_chunk_default(p);
+    return !hx_ks_x_applies(p, chunk) && !hx_ks_x_applies(p, nb % chunk ? nb % chunk : chunk);
+}
+
 int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t batch, int stage_mask,
                         hipEvent_t* ev) {
     if (!batch) return 0;

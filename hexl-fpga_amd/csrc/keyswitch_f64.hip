@@ -27,6 +27,7 @@ struct KsArgsF {
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
     u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
+    u32 overwrite;           // 1: `result` is written, not accumulated into (the host-pointer path: the HOST adds, fpga.cpp:441-475)
 };
 
 __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswitch.hip: XCD-contiguous work ranges
@@ -255,6 +256,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
         });
     }
     const u32 tB = u32(G::idxB(0, tid));
+    if (!G::HALF_ONLY && a.overwrite) {                           // host-pointer path: the output itself, canonical; the HOST adds
+#pragma unroll
+        for (int r = 0; r < G::E; ++r)
+            (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(hxf::reduce(hxf::mul_shoup(pv[r] - v[r], md.msf, md.msf_p, m), m), m));
+        return;
+    }
     u64 old[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) old[r] = (res + G::idxB(r, 0))[tB];
@@ -337,6 +344,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.range_flag = p->d_flag;
+    a.overwrite = p->overwrite_result ? 1u : 0u;
     // LAZY template argument = forward reduction period (f64_arith.hpp): 3 when every modulus <= 2^51(1+2^-7), 6 / 12
     // for moduli <= 2^50 / 2^49 (N = 16384 only; the smaller transforms keep 3), 0 = strict
     if (p->f64_lazy) {
