@@ -202,7 +202,7 @@ class KeySwitchPlan:
         return rc == 0
 
     def multiply_relinearize(self, out, a, b, batch: int):
-        """out[batch][2][L][n] = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), one fused pass (N = 1024, 8192, 16384)"""
+        """out[batch][2][L][n] = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), one fused pass (N = 1024 ... 16384)"""
         _check(lib().hexl_multiply_relinearize(self.h, _ptr(out), _ptr(a), _ptr(b), batch), "hexl_multiply_relinearize")
 
     def keyswitch_host(self, results, t_targets):

@@ -218,17 +218,27 @@ __device__ __forceinline__ void mac_keys_first(double (&acc0)[G::E], double (&ac
     }
 }
 
-// (x . y) mod p of two natural-order limbs as centred doubles in B register order (fused multiply + relinearize; direct
-// B-order loads, 16-coefficient geometry only). In-range operands: |x|, |y| <= p/2 after centring, |x.y mod p| <= 0.7p.
+// (x . y) mod p of two natural-order limbs as centred doubles in B register order (fused multiply + relinearize). In-range
+// operands: |x|, |y| <= p/2 after centring, |x.y mod p| <= 0.7p. Lanes that own at most four adjacent words load straight at the B
+// positions; otherwise both operands are read in A order (the product is element-wise: any common order will do) and the
+// product takes the cross-wave re-deal of load_natural_to_B.
 template <class G>
 __device__ __forceinline__ void load_product_to_B(double (&v)[G::E], const u64* __restrict__ x, const u64* __restrict__ y,
-                                                  int tid, const Mod m) {
-    static_assert(G::KL <= 2, "fused multiply + relinearize uses the 16-coefficient geometry");
-    const u32 tB = u32(G::idxB(0, tid));
+                                                  double* lds, int tid, const Mod m) {
+    if constexpr (G::KL <= 2) {
+        const u32 tB = u32(G::idxB(0, tid));
 #pragma unroll
-    for (int r = 0; r < G::E; ++r)
-        v[r] = hxf::reduce(hxf::mul_mod(hxf::reduce(hxf::to_f64((x + G::idxB(r, 0))[tB]), m),
-                                        hxf::reduce(hxf::to_f64((y + G::idxB(r, 0))[tB]), m), m), m);
+        for (int r = 0; r < G::E; ++r)
+            v[r] = hxf::reduce(hxf::mul_mod(hxf::reduce(hxf::to_f64((x + G::idxB(r, 0))[tB]), m),
+                                            hxf::reduce(hxf::to_f64((y + G::idxB(r, 0))[tB]), m), m), m);
+    } else {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r)
+            v[r] = hxf::reduce(hxf::mul_mod(hxf::reduce(hxf::to_f64((x + G::idxA(r, 0))[u32(tid)]), m),
+                                            hxf::reduce(hxf::to_f64((y + G::idxA(r, 0))[u32(tid)]), m), m), m);
+        redeal_x<G, false, true>(v, lds, tid, [](int r, int t) { return G::idxA(r, t); },
+                                 [](int r, int t) { return G::idxB(r, t); });
+    }
 }
 
 // position of register r / thread tid in a natural-order array about to enter an INVERSE transform (B order): direct
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
         double v[G::E];
         if constexpr (FUSED) {                                    // t_target[d] = a_1[d] . b_1[d]
             const size_t at = ((size_t(item / a.L) * 2 + 1) * a.L + d) * G::N;
-            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, md.m);
+            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, md.m);
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         } else if constexpr (G::KL <= 2) {
 #pragma unroll
@@ -389,8 +399,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);               // |w| <= 2.14p: |prod - w| <= 2.64p
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
-    if constexpr (FUSED_K >= 0) {
-        static_assert(G::KL <= 2, "fused multiply + relinearize uses the 16-coefficient geometry");
+    if constexpr (FUSED_K >= 0 && G::KL <= 2) {
         const u32 tB = u32(G::idxB(0, tid));
         auto ld = [&](const u64* p, int r) { return hxf::reduce(hxf::to_f64((p + G::idxB(r, 0))[tB]), m); };
 #pragma unroll
@@ -430,11 +439,17 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     double* const atA = lds + G::pad(G::idxA(0, tid));
     double* const atB = lds + G::pad(G::idxB(0, tid));
     __syncthreads();                                              // other waves may still read the last re-deal
+    // the value the output is added to, at A position r: the old result word, or (fused) component k of the ciphertext product
+    auto old_at_A = [&](int r) {
+        auto ld = [&](const u64* p) { return hxf::reduce(hxf::to_f64((p + G::idxA(r, 0))[u32(tid)]), m); };
+        if constexpr (FUSED_K == 0) return hxf::mul_mod(ld(a0), ld(b0), m);
+        else if constexpr (FUSED_K == 1) return hxf::reduce(hxf::mul_mod(ld(a0), ld(b1), m) + hxf::mul_mod(ld(a1), ld(b0), m), m);
+        else return hxf::reduce(hxf::to_f64_checked((res + G::idxA(r, 0))[u32(tid)], m, bad), m);
+    };
 #pragma unroll
-    for (int r0 = 0; r0 < G::E; r0 += 8) {
+    for (int r0 = 0; r0 < G::E; r0 += (FUSED_K == 1 ? 4 : 8)) {   // 8 (or 16: four operand streams) loads in flight at a time
 #pragma unroll
-        for (int r = r0; r < r0 + 8; ++r)
-            atA[G::pad(G::idxA(r, 0))] = hxf::reduce(hxf::to_f64_checked((res + G::idxA(r, 0))[u32(tid)], m, bad), m);
+        for (int r = r0; r < r0 + (FUSED_K == 1 ? 4 : 8); ++r) atA[G::pad(G::idxA(r, 0))] = old_at_A(r);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
             for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
             if constexpr (FUSED) {
                 const size_t at = ((size_t(b) * 2 + 1) * L + i) * G::N;
-                load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, tid, m);
+                load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, m);
             } else {
                 hxf::RangeMask ignore = 0;                              // (k_ksx_intt has checked this limb)
                 load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m, ignore);
@@ -658,10 +673,10 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
 }
 
 // fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry).
-// Ring dimensions whose partial pass leaves a lane at most four adjacent words (N = 1024, 8192, 16384): the operand limbs are
-// read straight at the transforms' B positions. (N = 2048 / 4096 would need the LDS re-deal of load_natural_to_B for five
-// operand streams; N = 32768 has no slot-major pipeline at all -- 64 registers of polynomial + 128 of accumulators do not fit
-// a 1024-thread workgroup.)
+// Where the partial pass leaves a lane at most four adjacent words (N = 1024, 8192, 16384) the operand limbs are read straight at
+// the transforms' B positions; N = 2048 / 4096 read them in A order and go through LDS (load_product_to_B, ksx_down_round).
+// (N = 32768 has no slot-major pipeline at all -- 64 registers of polynomial + 128 of accumulators do not fit a 1024-thread
+// workgroup.)
 template <int LOGN>
 static int mulrelin_for(hexl_ks_plan* p, const KsArgsX& a) {
     // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
@@ -682,6 +697,8 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
     a.range_flag = p->d_flag;
     switch (p->logn) {
         case 10: return mulrelin_for<10>(p, a);
+        case 11: return mulrelin_for<11>(p, a);
+        case 12: return mulrelin_for<12>(p, a);
         case 13: return mulrelin_for<13>(p, a);
         case 14: return mulrelin_for<14>(p, a);
         default: return HEXL_E_BADARG;

@@ -26,7 +26,8 @@ def composed(orc, case, a, b):
 
 
 @pytest.mark.parametrize("n,L,K,nb,strict", [(16384, 6, 7, 2, False), (16384, 7, 8, 96, False), (16384, 3, 4, 5, True),
-                                             (8192, 3, 4, 70, False), (1024, 2, 3, 300, False), (8192, 2, 3, 3, True)])
+                                             (8192, 3, 4, 70, False), (1024, 2, 3, 300, False), (8192, 2, 3, 3, True),
+                                             (2048, 2, 3, 150, False), (4096, 3, 4, 120, False), (4096, 2, 3, 4, True)])
 def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, n, L, K, nb, strict):
     moduli = primes_below(orc, K, 1 << 52, n) if strict else None      # just below 2^52: the strict FP64 kernels
     case = KsCase(orc, n, L, K, seed=40 + L, moduli=moduli)
@@ -49,13 +50,16 @@ def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, n, L, K, nb, strict):
 
 
 def test_rejects_what_it_does_not_cover(hx, ctx, dev, orc):
-    case = KsCase(orc, 4096, 2, 3, seed=1)
-    plan = hx.KeySwitchPlan(ctx, 4096, 2, 3, 3, 2, case.moduli, case.modswitch)
+    n = 32768                                                    # beyond the slot-major pipeline
+    case = KsCase(orc, n, 2, 3, seed=1)
+    plan = hx.KeySwitchPlan(ctx, n, 2, 3, 3, 2, case.moduli, case.modswitch)
     plan.set_keys(case.keys)
     import torch
-    z = torch.zeros(2 * 2 * 4096, dtype=torch.int64, device=dev)
+    z = torch.zeros(2 * 2 * n, dtype=torch.int64, device=dev)
+    z2 = torch.zeros(2 * 2 * n, dtype=torch.int64, device=dev)
+    z3 = torch.zeros(2 * 2 * n, dtype=torch.int64, device=dev)
     with pytest.raises(hx.HexlError):
-        plan.multiply_relinearize(z, z, z, 1)
+        plan.multiply_relinearize(z, z2, z3, 1)
     plan.close()
 
 
