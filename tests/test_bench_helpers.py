@@ -1,0 +1,44 @@
+"""CPU: the arithmetic behind bench.py's roofline block, without a GPU -- the algorithmic byte count of SURVEY 8d, the merge of
+PMC passes into per-keyswitch figures (tools/pmc_summary.derive, which bench.py's in-run passes go through), and the power
+sampler's behaviour on a box without the hwmon files."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tools")]
+
+
+def test_algorithmic_bytes_match_the_survey():
+    import bench
+    assert bench.ks_alg_bytes(16384, 7) == 4_587_520                  # 917,504 + 2 x 1,835,008
+    assert bench.ks_alg_bytes(16384, 6) == 3_932_160
+
+
+def test_pmc_passes_merge_into_per_keyswitch_figures():
+    import pmc_summary
+    batch, L = 256, 7
+    vals = {
+        "k_ksx_main<14, 4, 3, false>": {"SQ_INSTS_VALU": 3.6e8, "FETCH_SIZE": 1.0e6, "WRITE_SIZE": 5.0e5, "GRBM_GUI_ACTIVE": 8 * 2.0e6,
+                                         "SQ_WAVE_CYCLES": 2.0e9, "SQ_ACTIVE_INST_ANY": 4.0e8, "SQ_WAIT_INST_ANY": 7.0e8, "SQ_WAIT_ANY": 9.0e8},
+        "k_ksx_intt<14, 4, 3, false>": {"SQ_INSTS_VALU": 4.0e7, "FETCH_SIZE": 2.0e5, "WRITE_SIZE": 2.0e5, "GRBM_GUI_ACTIVE": 8 * 2.0e5},
+        "k_ntt_fwd_p<14, 4, 3>": {"SQ_INSTS_VALU": 1.0e7, "FETCH_SIZE": 1.0e5, "WRITE_SIZE": 1.0e5},     # not a keyswitch kernel
+    }
+    dur = {"k_ksx_main<14, 4, 3, false>": [1000.0, 1000.0], "k_ksx_intt<14, 4, 3, false>": [100.0], "k_ntt_fwd_p<14, 4, 3>": [80.0]}
+    d = pmc_summary.derive(vals, dur, batch, L, simds=1024)
+    assert d["valu_wave_instructions_per_keyswitch"] == (3.6e8 + 4.0e7) / batch
+    # FETCH_SIZE in KiB, doubled (gfx950 under-reports these kernels' reads by 2x); WRITE_SIZE in KiB as is
+    want = ((1.0e6 * 2 + 5.0e5) + (2.0e5 * 2 + 2.0e5)) * 1024 / batch
+    assert abs(d["traffic_bytes_per_keyswitch"] - want) < 1e-6
+    assert abs(d["shader_clock_ghz"] - 2.0) < 1e-9                      # (2.0e6 + 2.0e5) cycles per XCD over 1100 us
+    k = d["kernels"]["k_ksx_main<14, 4, 3, false>"]
+    assert abs(k["fp64_issue_frac"] - 3.6e8 * 4 / 1024 / 2.0e3 / 1000.0) < 1e-9
+    assert abs(sum(k["wave_time_split"].values()) - 1.0) < 1e-9
+    assert d["alg_bytes_per_keyswitch"] == 4_587_520 and "k_ntt_fwd_p<14, 4, 3>" not in d["kernels"]
+
+
+def test_power_sampler_without_hwmon_is_silent():
+    import bench
+    s = bench.PowerSampler(0)
+    s.dir = None                                                    # a box without the amdgpu hwmon files
+    s.start()
+    assert s.stop() is None
