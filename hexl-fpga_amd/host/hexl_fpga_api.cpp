@@ -30,6 +30,7 @@
 #include "../../include/hexl-fpga.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -214,9 +215,9 @@ void execute(Engine& e, Device& dev, const std::vector<Obj>& run) {
         // returns whatever its pipeline makes of it). Like an FPGA_ASSERT (fpga_assert.h:24-38) this is fatal only under
         // FPGA_DEBUG; otherwise say so once and carry on.
         if (e.debug) die("KeySwitch: a t_target word is not below its modulus", rc);
-        static bool said = false;
-        if (!said) std::fprintf(stderr, "[hexl-fpga/mi355x] warning: KeySwitch got a t_target word >= its modulus; the result of that object is unspecified\n");
-        said = true;
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            std::fprintf(stderr, "[hexl-fpga/mi355x] warning: KeySwitch got a t_target word >= its modulus; the result of that object is unspecified\n");
         return;
     }
     if (rc) die(kind_name[f.kind], rc);
@@ -256,9 +257,11 @@ void runner_loop(Engine* ep, size_t di) {
                 const bool closed = e.window_open[k] == 0 || e.closers[k] > 0 || avail < e.fifo.size() || avail >= e.max_run || timed_out;
                 if (avail >= share) { take = nd > 1 ? share : avail; break; }
                 if (closed) {
-                    // the remainder of a window: split it between the devices, but not into crumbs (a run has a fixed cost of
-                    // a few hundred microseconds: staging pipeline, launches, synchronisation)
-                    take = nd > 1 ? std::min(avail, std::max<size_t>(4, (avail + nd - 1) / nd)) : avail;
+                    // what is left of a window (less than a share): split it between the runners that are idle right now -- the
+                    // busy ones have their shares -- but not into crumbs (a run has a fixed cost of a few hundred microseconds:
+                    // staging pipeline, launches, synchronisation)
+                    const size_t idle = nd > (size_t)e.running_runs ? nd - (size_t)e.running_runs : 1;
+                    take = nd > 1 ? std::min(avail, std::max<size_t>(4, (avail + idle - 1) / idle)) : avail;
                     break;
                 }
                 // a window that is still being filled: objects arrive microseconds apart, wait for the share (bounded)
