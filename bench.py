@@ -468,6 +468,7 @@ def main():
         if ntt:
             extra["ntt_N16384_batch1024"] = ntt
         if not a.no_extra and world == 1:
+            extra["ntt_N16384_batch4096"] = time_ntt(hx, ctx, orc_mod, dev, 4096, 100)      # launch overhead amortised over 4x the work
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
             def other_shape(Lx, Kx, moduli=None, n=N):
                 cs = KsCase(orc_mod, n, Lx, Kx, seed=99, moduli=moduli)
