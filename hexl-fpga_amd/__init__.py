@@ -197,7 +197,7 @@ class KeySwitchPlan:
     def range_check(self) -> bool:
         """True if every keyswitch since the last check saw in-range words (syncs the stream, clears the flag)"""
         rc = lib().hexl_ks_range_check(self.h)
-        if rc not in (0, -4):
+        if rc not in (0, 1):                                       # 1 = HEXL_W_RANGE
             _check(rc, "hexl_ks_range_check")
         return rc == 0
 
@@ -209,7 +209,10 @@ class KeySwitchPlan:
         n = len(results)
         r = (_vp * n)(*[_ptr(a) for a in results])
         t = (_vp * n)(*[_ptr(a) for a in t_targets])
-        _check(lib().hexl_keyswitch_host(self.h, r, t, n), "hexl_keyswitch_host")
+        rc = lib().hexl_keyswitch_host(self.h, r, t, n)
+        if rc != 1:                                                # 1 = HEXL_W_RANGE: computed, some object had an out-of-range word
+            _check(rc, "hexl_keyswitch_host")
+        return rc == 0
 
     def time_stages(self, result, t_target, batch: int, iters: int):
         out = (ctypes.c_float * 4)()

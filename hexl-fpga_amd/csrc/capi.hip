@@ -213,6 +213,10 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         double qmax = 0;
         for (u64 i = 0; i < K; ++i) qmax = (double)h_moduli[i] > qmax ? (double)h_moduli[i] : qmax;
         p->f64_lazy = hxf::lazy_period_for(qmax);
+        double qmin = qmax;
+        for (u64 i = 0; i < K; ++i) qmin = (double)h_moduli[i] < qmin ? (double)h_moduli[i] : qmin;
+        const char* sk = getenv("HEXL_KSX_SKIP");                   // 0: keep the range reductions (tests)
+        p->x_skip = p->f64_lazy && qmax <= hxf::LAZY_SKIP_MAX_RATIO * qmin && !(sk && atoi(sk) == 0);
         const char* e = getenv("HEXL_KS_PERIOD");               // testing: force a SHORTER period (always valid)
         if (e && p->f64_lazy && atoi(e) > 0 && atoi(e) <= p->f64_lazy && (atoi(e) == 3 || atoi(e) == 6 || atoi(e) == 12))
             p->f64_lazy = atoi(e);
@@ -349,7 +353,7 @@ extern "C" int hexl_ks_range_check(hexl_ks_plan* p) {
     HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), c->stream));
     HX_CHECK(hipStreamSynchronize(c->stream));
-    return *p->h_flag ? HEXL_E_RANGE : 0;
+    return *p->h_flag ? HEXL_W_RANGE : 0;
 }
 
 extern "C" int hexl_multiply_relinearize(hexl_ks_plan* p, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b,
@@ -796,8 +800,16 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
                             h_t_targets[j] == h_t_targets[j - 1] + tt / 8; ++j) {}
             rc = hexl_keyswitch(p, h_results[i], h_t_targets[i], j - i);
         }
-        return rc ? rc : (int)hipStreamSynchronize(c->stream);
+        // the status covers this call, as on the staged path below: the kernels' range flag is read (and cleared) here too
+        if (!rc) rc = p->use_f64 ? hexl_ks_range_check(p) : (int)hipStreamSynchronize(c->stream);
+        return rc;
     }
+    // The FP64 kernels flag t_target words that are not below their modulus (the device-side result buffer starts at zero or
+    // is written here, so `result` is the host's business). The status covers THIS call: the flag is cleared on the stream
+    // before the first launch (whatever earlier hexl_keyswitch launches on the plan left in it is for hexl_ks_range_check,
+    // before this call), every sub-batch's launch is followed by a 4-byte copy of the still accumulating flag into the pinned
+    // mirror, and the pipeline's own last synchronisation covers the last copy -- no extra stream synchronisation per call.
+    if (p->use_f64) { *p->h_flag = 0; HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), c->stream)); }
     PipeShape sh{tt, rs, 0, sub_batch_for(tt + rs), false};
     // Like the reference, the device produces the keyswitch output only (the kernels accumulate into a zeroed
     // buffer) and the HOST adds it into the caller's result in submission order
@@ -825,6 +837,7 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
             p->overwrite_result = ow;
             const int rc = hexl_keyswitch(p, (u64*)dout, (u64*)d, cnt);
             p->overwrite_result = false;
+            if (!rc && p->use_f64) HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
             return rc;
         },
         [&](size_t first, size_t cnt, const char* h) {
@@ -838,7 +851,5 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
             else for (size_t b = 0; b < cnt; ++b) add_into(h_results[first + b], (const u64*)(h + b * rs));
         });
     if (rc_pipe) return rc_pipe;
-    // The FP64 kernels flag t_target words that are not below their modulus (the device-side result buffer starts at zero
-    // here, so `result` is the host's business). The pipeline has synchronised: the flag word comes with one more 4-byte copy.
-    return p->use_f64 ? hexl_ks_range_check(p) : 0;
+    return (p->use_f64 && *p->h_flag) ? HEXL_W_RANGE : 0;
 }

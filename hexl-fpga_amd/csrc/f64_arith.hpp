@@ -67,6 +67,15 @@ HX_HD double mul_mod(double a, double b, const Mod m) {
 
 // uint64 <-> double. to_f64 is exact for x < 2^53 (all in-domain data); from_f64 needs 0 <= x < 2^52.
 HX_HD double to_f64(uint64_t x) { return __builtin_fma((double)(uint32_t)(x >> 32), 4294967296.0, (double)(uint32_t)x); }
+// the same for words KNOWN to be below 2^52 (every in-range residue: moduli < 2^52): the word becomes the mantissa of
+// 2^52 + x (one 32-bit OR on the high half), one FP64 subtraction takes the 2^52 off again -- two instructions, one of them
+// at the 32-bit rate, instead of two conversions and an fma. A word >= 2^52 gives garbage (callers flag it, to_f64_checked).
+HX_HD double to_f64_lt52(uint64_t x) {
+    const uint64_t b = x | 0x4330000000000000ull;
+    double t;
+    __builtin_memcpy(&t, &b, 8);
+    return t - 4503599627370496.0;
+}
 HX_HD uint64_t from_f64(double x) {
     const double t = x + 4503599627370496.0;                 // 2^52: the integer lands in the mantissa
     uint64_t b;
@@ -84,6 +93,11 @@ __device__ __forceinline__ double to_f64_checked(uint64_t x, const Mod m, RangeM
     const double d = to_f64(x);
     out_of_range |= __builtin_amdgcn_ballot_w64(!(d < m.p));
     return d;
+}
+// the two-instruction conversion with the range check on the integer word (q = the modulus as an integer, < 2^52)
+__device__ __forceinline__ double to_f64_lt52_checked(uint64_t x, uint64_t q, RangeMask& out_of_range) {
+    out_of_range |= __builtin_amdgcn_ballot_w64(x >= q);
+    return to_f64_lt52(x);
 }
 __device__ __forceinline__ void report_range(RangeMask out_of_range, unsigned* flag) {
     if (out_of_range != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
@@ -136,6 +150,26 @@ HX_HD void gs_bfly_lazy(double& X, double& Y, double w, double wp, const Mod m) 
     X = reduce(s, m);
     Y = mul_shoup(d, w, wp, m);
 }
+// Inverse butterflies WITHOUT the w/p table (round 4): the quotient comes from the product itself, as in the forward
+// transforms -- same instruction count, half the per-lane twiddle bytes and registers of an inverse pass.
+//   bound chain, top tier (a = p 2^-53 = 0.252): a product output is <= (0.5 + 0.378 |d|/p) p with |d| = |X - Y| <= 2 y when
+//   both inputs are product outputs of the previous stage (<= y p):  y -> 0.5 + 0.756 y = 0.5, 0.878, 1.164, 1.380, 1.543, 1.667,
+//   1.760, 1.831, ... -> 2.05: |d| would pass 2^53 = 3.97p after twelve stages. One stage (INV_NOWP_STRICT_STAGE, the 6th
+//   global stage of every transform that has more) reduces its product outputs as well, which restarts the chain: at most
+//   eight lazy stages follow (n <= 2^15), y <= 1.884, |d| <= 3.77p. Lower tiers (a <= 0.125): y -> 0.5 + 0.375 y <= 0.8.
+//   exactness of mul_mod: |h - k p| <= (0.5 + 0.252 |d|/p) p <= 1.5p. The last stage (n^-1 folded in) keeps mul_shoup on
+//   scalar constants. tests/cpp/f64_selftest.cpp replays the schedule against the oracle and tracks the largest |x|.
+constexpr int INV_NOWP_STRICT_STAGE = 6;
+HX_HD void gs_bfly_lazy_nowp(double& X, double& Y, double w, const Mod m) {
+    const double s = X + Y, d = X - Y;
+    X = reduce(s, m);
+    Y = mul_mod(d, w, m);
+}
+HX_HD void gs_bfly_nowp(double& X, double& Y, double w, const Mod m) {     // both outputs centred (strict kernels; the strict stage)
+    const double s = X + Y, d = X - Y;
+    X = reduce(s, m);
+    Y = reduce(mul_mod(d, w, m), m);
+}
 // Folded multiply-accumulate (LAZY regime; the key multiply-accumulate of the slot-major keyswitch): acc + x*k mod p in
 // EIGHT operations instead of mul_mod + add + reduce = ten -- the accumulator enters the quotient estimate, so the result
 // is reduced in the same step:  acc' = (h - K p) + (acc + l),  K = rint(fl(h/p) + acc/p),  h + l = x*k exactly.
@@ -151,8 +185,18 @@ HX_HD double mac_fold(double acc, double x, double k, const Mod m) {
     return __builtin_fma(-K, m.p, h) + s;
 }
 
-// forward schedule: reduce every element after global stage s (1-based) when s % period == 0 or s is the last stage
-HX_HD constexpr bool lazy_fwd_reduce_after(int s, int logn, int period = 3) { return (s % period == 0) || (s == logn); }
+// forward schedule: reduce every element after global stage s (1-based) when (s + shift) % period == 0 or s is the last stage.
+// shift = 1 (round 4, the mod-up transforms of the slot-major keyswitch) is the schedule for inputs that are NOT centred:
+// canonical residues of a neighbouring modulus, |x| <= rho p with rho = max q / min q <= LAZY_SKIP_MAX_RATIO, taken as they
+// are (no range reduction of the input). The first group is one stage shorter, every later one is a full period:
+//   top tier (growth c -> 1.378 c + 0.5, limit 3.97): 1.25 -> 2.22 -> 3.56 | 0.5 -> ... -> 3.45 | ...; an un-reduced tail is at
+//   most `period` stages (3.45p; 6.22p / 11.8p in the lower tiers), which mac_fold accepts (its bounds only need
+//   |x k| < 2^103 and |x k / p| < 2^52).  period 6 (1.1875 c + 0.5, limit 8): 1.25 -> 6.58 after five stages; period 12
+//   (1.09375 c + 0.5, limit 16): 1.25 -> 12.3 after eleven.
+HX_HD constexpr bool lazy_fwd_reduce_after(int s, int logn, int period = 3, int shift = 0) {
+    return ((s + shift) % period == 0) || (s == logn);
+}
+constexpr double LAZY_SKIP_MAX_RATIO = 1.25;
 
 // Smaller moduli leave more head room: with a = p * 2^-53 a forward butterfly grows the bound as
 // c -> (1 + 1.5a) c + 0.5 and every value must stay below c = 1/a (|x| < 2^53):

@@ -111,6 +111,8 @@ struct hexl_ks_plan {
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     u32* d_flag = nullptr;            // one device word + its pinned host mirror: input-range flag (HEXL_KS_VALIDATE)
     u32* h_flag = nullptr;
+    bool x_skip = false;              // slot-major lazy kernels: moduli within LAZY_SKIP_MAX_RATIO of each other -> c_d and s' enter the
+                                      // transforms without a range reduction (keyswitch_x.hip SKIP variants; HEXL_KSX_SKIP=0 turns it off)
     bool overwrite_result = false;    // host-pointer path, (b, d)-major FP64 kernels: write `result` instead of accumulating into it
     hipStream_t cur = nullptr;        // stream the chunk being launched goes to
     u64* cur_scratch = nullptr;

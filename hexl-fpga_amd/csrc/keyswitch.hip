@@ -436,7 +436,8 @@ size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
 // HEXL_KS_VALIDATE=1: the keyswitch precondition (every t_target / result word below its modulus), checked on the device
 __global__ void k_ks_validate(const u64* __restrict__ t, const u64* __restrict__ res, const KsModulus* __restrict__ mods,
                               u32 L, u32 n, size_t batch, u32* __restrict__ bad) {
-    const size_t per_t = size_t(L) * n, per_r = 2 * per_t, total = batch * (per_t + per_r);
+    // res == nullptr: the call WRITES `result` (host-pointer path on the overwrite kernels): only t_target is an input
+    const size_t per_t = size_t(L) * n, per_r = 2 * per_t, total = batch * (per_t + (res ? per_r : 0));
     bool out = false;
     for (size_t g = size_t(blockIdx.x) * blockDim.x + threadIdx.x; g < total; g += size_t(gridDim.x) * blockDim.x) {
         u64 word; u32 limb;
@@ -448,13 +449,14 @@ __global__ void k_ks_validate(const u64* __restrict__ t, const u64* __restrict__
 }
 
 static int validate_inputs(hexl_ks_plan* p, const u64* d_result, const u64* d_t_target, size_t batch) {
-    // one flag word per plan, allocated once, with a pinned host mirror (no hipMalloc / hipFree per call, nothing to leak on
-    // an error path, no asynchronous copy into pageable memory)
     // the plan's flag word and its pinned host mirror (allocated with the plan: nothing to allocate, free or leak per call, no
-    // asynchronous copy into pageable memory). It is shared with the kernels' own range flag: a violation found here is
-    // reported here and the flag left clean.
-    HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), p->ctx->stream));
-    hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, d_result, p->d_mods, p->L, p->n, batch, p->d_flag);
+    // asynchronous copy into pageable memory). It is shared with the kernels' own range flag and ORs into it: a violation an
+    // earlier launch on this plan has flagged and nobody has read yet (hexl_ks_range_check) is reported here as well instead
+    // of being wiped; the flag is left clean either way.
+    // A call that WRITES its result (overwrite_result: the staging buffer of the host-pointer path is uninitialised on
+    // purpose) has only t_target as input.
+    hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, p->overwrite_result ? nullptr : d_result,
+                       p->d_mods, p->L, p->n, batch, p->d_flag);
     HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
     HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), p->ctx->stream));
     HX_CHECK(hipStreamSynchronize(p->ctx->stream));

@@ -30,6 +30,14 @@
 //  * The NEXT round's input is requested inside the multiply-accumulate, into the registers the products free.
 //  * Per-lane twiddles are requested by hand ahead of their butterflies (KX_PRE, KX_IPRE): with 96 data registers the
 //    compiler otherwise puts each load in front of its first use and waits for it on the spot.
+//  * Round 4, instructions that were not needed (the pipeline is bound by FP64 issue): when the moduli of a
+//    plan are within a factor LAZY_SKIP_MAX_RATIO of each other (SKIP kernels; always true for the reference's parameter sets
+//    of equal-sized primes) c_d enters the mod-up transforms as it is -- canonical below q_d, i.e. at most 1.25 q_i -- on a
+//    reduction schedule shifted by one stage (f64_arith.hpp), instead of being range-reduced first; s' is stored as the
+//    exact centred remainder y = s'_canonical - floor(q_sp/2) (what intt2_redu.hpp's "+ fix" turns it into anyway), so the
+//    mod-down transforms take it as it is too; the d == i term and the accumulators go un-reduced into mac_fold / the mod-down
+//    epilogue (bounds there); 64-bit words become doubles by an OR and a subtraction; the inverse transforms take their
+//    quotients from the products (no w/p table: half the per-lane twiddle bytes). 5.7 % fewer VALU instructions per keyswitch.
 #include <stdlib.h>
 
 #include "hexl_internal.hpp"
@@ -67,6 +75,17 @@ using namespace hx;
 // (N = 16384) implies and the smaller ring dimensions (512 ... 64 threads, several workgroups per CU) have to ask for
 #define KX_WAVES(LOGE) ((LOGE) == 4 ? 4 : 2)
 
+// Profiling aids (WRONG RESULTS; -DHEXL_PROFILING_AIDS builds only: lib/libhexl_mi355x_prof.so, never the shipped library):
+// HEXL_KSX_ALIAS=<bit mask> makes every workgroup read one instance's / limb's rows of a stream, which takes that stream out
+// of the L2-miss-side counters and of the fabric's power draw (profiles/r04_bytes.json): 1 = key rows (every row reads row 0),
+// 2 = c and s' reads (instance 0), 4 = t_target reads (instance 0), 8 = result read-modify-write (instance 0), 16 = twiddle
+// tables (limb 0). HEXL_KSX_KEY_ALIAS=1 is the old name of bit 1.
+#ifdef HEXL_PROFILING_AIDS
+#define KX_ALIASED(bit, x) ((a.alias & (bit)) ? 0u : (x))
+#else
+#define KX_ALIASED(bit, x) (x)
+#endif
+
 struct KsArgsX {
     const KsModF64* mods;    // [K]
     const double* tables;    // [K][4][n]: w, w/p, inverse w (first entry at index 1), inverse w/p
@@ -77,8 +96,8 @@ struct KsArgsX {
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
     u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
-    u32 key_stride;          // words between key[d][slot] rows: 2 n. (Profiling aid HEXL_KSX_KEY_ALIAS=1, WRONG RESULTS: 0, every key
-                             // row reads row 0, which takes the key stream out of the L2-miss-side counters -- bench.py's DRAM-side estimate)
+    u32 key_stride;          // words between key[d][slot] rows: 2 n (profiling builds, alias bit 1: 0)
+    u32 alias;               // profiling builds only (KX_ALIASED); 0 in the shipped library
     // fused multiply + relinearize (hexl_multiply_relinearize): ciphertext pairs a, b [chunk][2][L][n]; the keyswitch input
     // is a_1 . b_1 (never stored) and `result` is WRITTEN with (a_0 b_0, a_0 b_1 + a_1 b_0) + keyswitch(a_1 b_1)
     const u64 *mul_a, *mul_b;
@@ -197,7 +216,10 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
 // are requested straight into their registers, right behind the E words of t_i and before anything is waited for -- one
 // memory latency for the whole phase. (Through the three-deep ring this phase took 22 k cycles, twice a later round's:
 // all 16 waves are in it at the same time, nobody has transform work to cover the ring's short reach.)
-template <class G>
+// LAZYFOLD (lazy kernels with the folded multiply-accumulate): nothing is range-reduced here -- t_i < q_i as it comes
+// (k_ksx_intt has checked these very words), |t_i . key mod p| <= (0.5 + 0.378) p = 0.88p by mul_mod's general bound, which
+// mac_fold accepts as an accumulator (|acc| <= 1.6p).
+template <class G, bool LAZYFOLD = false>
 __device__ __forceinline__ void mac_keys_first(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
                                                const u64* __restrict__ t, const double* __restrict__ k0,
                                                const double* __restrict__ next, int tid, const Mod m) {
@@ -211,10 +233,16 @@ __device__ __forceinline__ void mac_keys_first(double (&acc0)[G::E], double (&ac
     for (int r = 0; r < G::E; ++r) { acc0[r] = keys.at(toff, r * G::T * 8); acc1[r] = keys.at(toff, (G::N + r * G::T) * 8); }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
-        const double x = hxf::reduce(hxf::to_f64(raw[r]), m);
         v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
-        acc0[r] = hxf::reduce(hxf::mul_mod(x, acc0[r], m), m);
-        acc1[r] = hxf::reduce(hxf::mul_mod(x, acc1[r], m), m);
+        if constexpr (LAZYFOLD) {
+            const double x = hxf::to_f64_lt52(raw[r]);
+            acc0[r] = hxf::mul_mod(x, acc0[r], m);
+            acc1[r] = hxf::mul_mod(x, acc1[r], m);
+        } else {
+            const double x = hxf::reduce(hxf::to_f64(raw[r]), m);
+            acc0[r] = hxf::reduce(hxf::mul_mod(x, acc0[r], m), m);
+            acc1[r] = hxf::reduce(hxf::mul_mod(x, acc1[r], m), m);
+        }
     }
 }
 
@@ -247,14 +275,20 @@ template <class G>
 __device__ __forceinline__ int in_pos(int r, int tid) { return G::KL <= 2 ? G::idxB(r, tid) : G::idxA(r, tid); }
 
 // ---- special slot: steps 1-4 for one instance -------------------------------------------------------------------
-// step 4 for one k: s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2) (mod q_sp), canonical   (intt2_redu.hpp:25,43)
+// step 4 for one k. The reference forms s'_k = INTT_{q_sp}(prod[k][special]) + floor(q_sp/2) (mod q_sp), canonical
+// (intt2_redu.hpp:25,43), and every limb i then uses (s'_k + fix_i) mod q_i with fix_i = -floor(q_sp/2) mod q_i
+// (intt2_redu.hpp:31-32, 49-51) -- that is, y_k = s'_k - floor(q_sp/2), the EXACT centred remainder of the inverse transform's
+// output in [-floor(q_sp/2), floor(q_sp/2)]. The scratch holds y_k (a signed integer in a double): k_ksx_main needs neither
+// the addition nor, when the moduli are of one size, a range reduction (|y_k| <= 0.5 rho q_i).
 template <class G, class W>
 __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __restrict__ dst, double* lds, int tid,
                                                  const double* ts, const KsModF64& msp) {
     W::template inverse<false>(v, lds, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
 #pragma unroll
-    for (int r = 0; r < G::E; ++r)
-        (dst + G::idxA(r, 0))[u32(tid)] = hxf::lift(hxf::reduce(hxf::lift(v[r], msp.m) + msp.half, msp.m), msp.m);
+    for (int r = 0; r < G::E; ++r) {
+        const double c = hxf::lift(v[r], msp.m);                   // canonical [0, q_sp)
+        (dst + G::idxA(r, 0))[u32(tid)] = c > msp.half ? c - msp.m.p : c;
+    }
 }
 
 // step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles in natural order, one workgroup per (instance, limb).
@@ -264,7 +298,7 @@ __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __re
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, 0>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>;         // inverse without the w/p table
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.L);
     if (wk.pos >= wk.end) return;
@@ -272,7 +306,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
     // transform (WgNttF64::inverse's `before_uniform` hook; see k_ntt_inv_p): the item loop never waits for its input
     auto src_of = [&](u32 item) -> const u64* {
         if constexpr (FUSED) return nullptr;
-        else return a.t_target + size_t(item) * G::N;
+        else return a.t_target + size_t(KX_ALIASED(4, item / a.L) * a.L + item % a.L) * G::N;
     };
     u64 raw[G::E];
     hxf::RangeMask bad = 0;                                             // a t_target word >= its modulus (FP64 precondition)
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
         asm volatile("" : "+v"(tid));
         const u32 d = __builtin_amdgcn_readfirstlane(item % a.L);
         const KsModF64 md = a.mods[d];
-        u32 toff = d * 4 * G::N;
+        u32 toff = KX_ALIASED(16, d) * 4 * G::N;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         double v[G::E];
@@ -297,8 +331,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
             load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, md.m);
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         } else if constexpr (G::KL <= 2) {
+            // canonical words as they are: the first inverse stage takes X + Y < 2p and |X - Y| < p (f64_arith.hpp)
+            const u64 qd = (u64)md.m.p;
 #pragma unroll
-            for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64_checked(raw[r], md.m, bad), md.m);
+            for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked(raw[r], qd, bad);
             const u32 nitem = item + wk.step < wk.end ? item + wk.step : item;       // (last round: a harmless re-read)
             const u64* pn = src_of(nitem);
             const u32 tB = u32(G::idxB(0, tid));
@@ -320,10 +356,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
 
 // steps 2-4 for the special slot of one instance: acc_k = sum_d NTT_{q_sp}(c_d mod q_sp) . key[d][special][k], then
 // s'_k = INTT_{q_sp}(acc_k) + floor(q_sp/2)
-template <int LOGN, int LOGE, int LAZY>
+// SKIP (lazy kernels, moduli within LAZY_SKIP_MAX_RATIO of each other): c_d enters the transform as it is, on the shifted schedule
+template <int LOGN, int LOGE, int LAZY, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;
+    static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, true>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const double* c0 = a.c + size_t(b) * L * G::N;
+        const double* c0 = a.c + size_t(KX_ALIASED(2, b)) * L * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = (c0 + G::idxA(r, 0))[u32(tid)]; }
     }
@@ -347,18 +385,20 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     for (u32 it = 0; it < L; ++it) {
         int tid = threadIdx.x;                                    // laundered per round (see k_ksf_up)
         asm volatile("" : "+v"(tid));
-        u32 tsp = isp * 4 * G::N;
+        u32 tsp = KX_ALIASED(16, isp) * 4 * G::N;
         asm volatile("" : "+s"(tsp));
         const double* ts = a.tables + tsp;
         KX_STAMP(4 * it + 0);
+        if constexpr (!SKIP) {
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], msp.m);                 // intt1_redu.hpp:36-42
+            for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], msp.m);             // intt1_redu.hpp:36-42
+        }
         KX_STAMP(4 * it + 1);
         const double* k0 = key_row<G>(a, it, L);
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
         KX_STAMP(4 * it + 2);
-        mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * G::N, tid, msp.m);
+        mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, a.c + (size_t(KX_ALIASED(2, b)) * L + nd) * G::N, tid, msp.m);
     }
     if constexpr (LAZY != 0 && KX_FOLD) {
 #pragma unroll
@@ -367,7 +407,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        u32 tsp = isp * 4 * G::N;
+        u32 tsp = KX_ALIASED(16, isp) * 4 * G::N;
         asm volatile("" : "+s"(tsp));
         KX_STAMP(4 * L + 0);
         ksx_special_down<G, W>(acc0, a.s + (size_t(b) * 2 + 0) * G::N, ldsx, tid, a.tables + tsp, msp);
@@ -375,7 +415,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        u32 tsp = isp * 4 * G::N;
+        u32 tsp = KX_ALIASED(16, isp) * 4 * G::N;
         asm volatile("" : "+s"(tsp));
         KX_STAMP(4 * L + 4);
         ksx_special_down<G, W>(acc1, a.s + (size_t(b) * 2 + 1) * G::N, ldsx, tid, a.tables + tsp, msp);
@@ -388,15 +428,21 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 // steps 5-7 for one k: w = NTT((s'_k + fix_i) mod q_i) from the raw s'_k words in v (A order); result[k][i] += (acc - w) * msf_i
 // FUSED (k = 0, 1): the "old result" is component k of the ciphertext product, formed here from the operand limbs
 // (a0, a1, b0, b1 of this limb, natural order): k = 0: a0 b0; k = 1: a0 b1 + a1 b0; `res` is written, not accumulated into
-template <class G, class W, int FUSED_K = -1>
+// v holds y_k = s'_k - floor(q_sp/2) (ksx_special_down), which IS (s'_k + fix_i) mod q_i of intt2_redu.hpp:49-51 up to a
+// multiple of q_i. SKIP: |y_k| <= 0.5 rho q_i goes into the transform as it is (standard schedule: 0.625 -> 3.77 after three
+// stages at rho = 1.25). The accumulators arrive un-reduced from mac_fold in the lazy kernels (|acc| <= 1.7p):
+// |acc - w| <= 1.7p + 2.14p = 3.84p < 2^53 = 3.97p, and mul_shoup of that is exact (|h| < 2^103, |h - k p| <= 1.5p).
+template <class G, class W, int FUSED_K = -1, bool SKIP = false>
 __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
                                                double* lds, int tid, const double* tb, const KsModF64& md, hxf::RangeMask& bad,
                                                const u64* a0 = nullptr, const u64* a1 = nullptr, const u64* b0 = nullptr,
                                                const u64* b1 = nullptr) {
     const Mod m = md.m;
+    if constexpr (!SKIP) {
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r] + md.fix, m);             // intt2_redu.hpp:49-51
-    W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);               // |w| <= 2.14p: |prod - w| <= 2.64p
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
+    }
+    W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);               // |w| <= 2.14p
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
     if constexpr (FUSED_K >= 0 && G::KL <= 2) {
@@ -422,11 +468,12 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
 #pragma unroll
         for (int r0 = 0; r0 < G::E; r0 += G::E / 2) {
             u64 old[G::E / 2];
+            const u64 qi = (u64)m.p;
 #pragma unroll
             for (int r = 0; r < G::E / 2; ++r) old[r] = (res + G::idxB(r0 + r, 0))[tB];
 #pragma unroll
             for (int r = 0; r < G::E / 2; ++r) {
-                const double rr = hxf::reduce(hxf::to_f64_checked(old[r], m, bad) + v[r0 + r], m);   // fpga.cpp:453-457
+                const double rr = hxf::reduce(hxf::to_f64_lt52_checked(old[r], qi, bad) + v[r0 + r], m);   // fpga.cpp:453-457
                 (res + G::idxB(r0 + r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -463,10 +510,13 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     for (int r = 0; r < G::E; ++r) (res + G::idxA(r, 0))[u32(tid)] = hxf::from_f64(atA[G::pad(G::idxA(r, 0))]);
 }
 
-template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;
+    static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;                    // mod-down transforms: centred input
+    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0>;     // mod-up transforms (SKIP: canonical c_d as it is)
+    constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler
@@ -490,7 +540,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     const KsModF64 md = a.mods[i];
     const Mod m = md.m;
     // round `it` reads c_it (it < L, skipping it == i) or s'_{it-L}
-    auto round_src = [&](u32 it) { return it < L ? a.c + (size_t(b) * L + it) * G::N : a.s + (size_t(b) * 2 + (it - L)) * G::N; };
+    const u32 bc = KX_ALIASED(2, b), bt = KX_ALIASED(4, b), br = KX_ALIASED(8, b);
+    auto round_src = [&](u32 it) { return it < L ? a.c + (size_t(bc) * L + it) * G::N : a.s + (size_t(bc) * 2 + (it - L)) * G::N; };
     const u32 first = i == 0 ? 1u : 0u;
     double acc0[G::E], acc1[G::E];
     double v[G::E];                                               // between rounds: the next round's input, A order
@@ -502,7 +553,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         KX_STAMP(60);
         if constexpr (!FUSED && G::KL <= 2 && KX_FIRST_DIRECT) {
             KX_STAMP(61);
-            mac_keys_first<G>(acc0, acc1, v, a.t_target + (size_t(b) * L + i) * G::N, k0, round_src(first), tid, m);
+            mac_keys_first<G, LAZYFOLD>(acc0, acc1, v, a.t_target + (size_t(bt) * L + i) * G::N, k0, round_src(first), tid, m);
         } else {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
@@ -511,7 +562,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
                 load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, m);
             } else {
                 hxf::RangeMask ignore = 0;                              // (k_ksx_intt has checked this limb)
-                load_natural_to_B<G>(v, a.t_target + (size_t(b) * L + i) * G::N, ldsx, tid, m, ignore);
+                load_natural_to_B<G>(v, a.t_target + (size_t(bt) * L + i) * G::N, ldsx, tid, m, ignore);
             }
             KX_STAMP(61);
             mac_keys<G>(acc0, acc1, v, k0, round_src(first), tid, m);
@@ -522,38 +573,37 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     for (u32 it = first; it < L;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        u32 toff = i * 4 * G::N;
+        u32 toff = KX_ALIASED(16, i) * 4 * G::N;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         KX_STAMP(4 * it + 0);
+        if constexpr (!SKIP) {
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);                 // intt1_redu.hpp:36-42
+            for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);             // intt1_redu.hpp:36-42
+        }
         KX_STAMP(4 * it + 1);
         u32 nit = it + 1;
         if (nit == i) ++nit;
         const double* k0 = key_row<G>(a, it, i);
-        W::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);          // |u| <= 2.14p
+        WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);         // |u| <= 2.14p (SKIP: 3.45p)
         KX_STAMP(4 * it + 2);
-        mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, round_src(nit), tid, m);   // nit <= L: s'_0 follows the last c_d
+        mac_keys<G, LAZYFOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
         it = nit;
     }
-    if constexpr (LAZY != 0 && KX_FOLD) {
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
-    }
+    // (lazy kernels: the accumulators stay as mac_fold leaves them, |acc| <= 1.7p -- ksx_down_round)
     // rounds L, L+1 (k = 0, 1)
     hxf::RangeMask bad = 0;                                             // a result word >= its modulus (FP64 precondition)
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        u32 toff = i * 4 * G::N;
+        u32 toff = KX_ALIASED(16, i) * 4 * G::N;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         KX_STAMP(4 * L + 0);
-        const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * G::N;
-        if constexpr (FUSED) ksx_down_round<G, W, 0>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
-        const double* nxt = a.s + (size_t(b) * 2 + 1) * G::N;
+        const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
+        if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
+        else ksx_down_round<G, W, -1, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
+        const double* nxt = a.s + (size_t(bc) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
         KX_STAMP(4 * L + 4);
@@ -561,12 +611,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        u32 toff = i * 4 * G::N;
+        u32 toff = KX_ALIASED(16, i) * 4 * G::N;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * G::N;
-        if constexpr (FUSED) ksx_down_round<G, W, 1>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
+        const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
+        if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
+        else ksx_down_round<G, W, -1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
         KX_STAMP(4 * L + 8);
         hxf::report_range(bad, a.range_flag);
     }
@@ -580,14 +630,14 @@ static int set_lds_x(K kern, size_t bytes) {
     return 0;
 }
 
-template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
 static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
-            int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY>, G::LDS_USED);
+            int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY, SKIP>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksx_intt<LOGN, LOGE, LAZY, FUSED>, G::LDS_USED);
-            if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>, G::LDS_USED);
             return rc;
         }))
         return rc0;
@@ -607,10 +657,10 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
         hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY, FUSED>), grid_for(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2)
-        hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY, SKIP>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
     if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED>), KX_MAIN_PERSIST ? grid_for(a.nb * a.L) : dim3(a.nb * a.L), dim3(G::T),
+        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>), KX_MAIN_PERSIST ? grid_for(a.nb * a.L) : dim3(a.nb * a.L), dim3(G::T),
                            G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
@@ -636,7 +686,23 @@ bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
 template <int LOGN>
 static int launch_x_small(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
     // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
-    return p->f64_lazy ? run_chunk_x<LOGN, 4, 3>(p, a, stage_mask, ev) : run_chunk_x<LOGN, 4, 0>(p, a, stage_mask, ev);
+    if (!p->f64_lazy) return run_chunk_x<LOGN, 4, 0>(p, a, stage_mask, ev);
+    return p->x_skip ? run_chunk_x<LOGN, 4, 3, false, true>(p, a, stage_mask, ev) : run_chunk_x<LOGN, 4, 3>(p, a, stage_mask, ev);
+}
+
+// the plan's alias mask (profiling builds only; the shipped library ignores the variables)
+static u32 ksx_alias_mask() {
+#ifdef HEXL_PROFILING_AIDS
+    static const u32 mask = [] {
+        const char *e = getenv("HEXL_KSX_ALIAS"), *k = getenv("HEXL_KSX_KEY_ALIAS");
+        const u32 m = (e ? (u32)atoi(e) : 0u) | ((k && atoi(k) == 1) ? 1u : 0u);
+        if (m) fprintf(stderr, "[hexl_mi355x PROFILING BUILD] HEXL_KSX_ALIAS=%u: keyswitch results are WRONG by design\n", m);
+        return m;
+    }();
+    return mask;
+#else
+    return 0u;
+#endif
 }
 
 int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
@@ -650,8 +716,8 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = a.mul_b = nullptr;
     a.stamps = nullptr;
-    static const u32 alias = [] { const char* e = getenv("HEXL_KSX_KEY_ALIAS"); return (e && atoi(e) == 1) ? 1u : 0u; }();
-    a.key_stride = alias ? 0u : u32(2 * n);
+    a.alias = ksx_alias_mask();
+    a.key_stride = (a.alias & 1u) ? 0u : u32(2 * n);
     a.range_flag = p->d_flag;
     switch (p->logn) {
         case 10: return launch_x_small<10>(p, a, stage_mask, ev);
@@ -664,10 +730,13 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     // LAZY template argument = forward reduction period of the transforms (f64_arith.hpp), as in keyswitch_f64.hip
     if (p->x_loge == 5)                                           // 32 coefficients x 512 threads: measured slower, kept for study
         return p->f64_lazy ? run_chunk_x<14, 5, 3>(p, a, stage_mask, ev) : run_chunk_x<14, 5, 0>(p, a, stage_mask, ev);
-    switch (p->f64_lazy) {
-        case 12: return run_chunk_x<14, 4, 12>(p, a, stage_mask, ev);
-        case 6:  return run_chunk_x<14, 4, 6>(p, a, stage_mask, ev);
-        case 3:  return run_chunk_x<14, 4, 3>(p, a, stage_mask, ev);
+    switch (p->f64_lazy * 2 + (p->x_skip ? 1 : 0)) {
+        case 25: return run_chunk_x<14, 4, 12, false, true>(p, a, stage_mask, ev);
+        case 24: return run_chunk_x<14, 4, 12>(p, a, stage_mask, ev);
+        case 13: return run_chunk_x<14, 4, 6, false, true>(p, a, stage_mask, ev);
+        case 12: return run_chunk_x<14, 4, 6>(p, a, stage_mask, ev);
+        case 7:  return run_chunk_x<14, 4, 3, false, true>(p, a, stage_mask, ev);
+        case 6:  return run_chunk_x<14, 4, 3>(p, a, stage_mask, ev);
         default: return run_chunk_x<14, 4, 0>(p, a, stage_mask, ev);
     }
 }
@@ -680,7 +749,8 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
 template <int LOGN>
 static int mulrelin_for(hexl_ks_plan* p, const KsArgsX& a) {
     // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
-    return p->f64_lazy ? run_chunk_x<LOGN, 4, 3, true>(p, a, 7, nullptr) : run_chunk_x<LOGN, 4, 0, true>(p, a, 7, nullptr);
+    if (!p->f64_lazy) return run_chunk_x<LOGN, 4, 0, true>(p, a, 7, nullptr);
+    return p->x_skip ? run_chunk_x<LOGN, 4, 3, true, true>(p, a, 7, nullptr) : run_chunk_x<LOGN, 4, 3, true>(p, a, 7, nullptr);
 }
 int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t nb) {
     const size_t n = p->n, L = p->L;
@@ -693,6 +763,7 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = d_a; a.mul_b = d_b;
     a.stamps = nullptr;
+    a.alias = 0;
     a.key_stride = u32(2 * n);
     a.range_flag = p->d_flag;
     switch (p->logn) {

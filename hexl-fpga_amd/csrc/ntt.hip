@@ -26,7 +26,7 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // index 0 is never read by either transform; its thread resets the counter a launch 32 launches from now will use
-    if (i == 0) { w[0] = 0.0; wp[0] = 0.0; *zero_for_later = 0; return; }
+    if (i == 0) { w[0] = 0.0; *zero_for_later = 0; return; }
     const u64 r = roots[i], p = precon[i];
     // 128-bit  D = r*2^64 - p*q  must satisfy 0 <= D < q
     const u64 lo = p * q, hi = mulhi(p, q);
@@ -36,8 +36,7 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     const double pd = (double)q;
     const u64 rr = r < q ? r : 0;
     const double c = rr > q / 2 ? (double)rr - pd : (double)rr;
-    w[i] = c;
-    wp[i] = c / pd;
+    w[i] = c;          // (no w/p table: both transforms take their quotients from the products, f64_arith.hpp)
 }
 
 // Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
@@ -81,6 +80,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     const u32 p = blockIdx.x;
     if (p >= batch) return;
     u64* px = x + size_t(p) * G::N;
+    // tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones) are known at kernel
+    // entry and wave-uniform: straight to the integer butterflies, no FP64 transform first (round 4)
+    if (*violations != 0) { slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q); return; }
     const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
     const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
     WgNttF64<LOGN, LOGE, LAZY>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
-    const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);
+    const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
     const u32 p = blockIdx.x;
     if (p >= batch) return;
     u64* px = x + size_t(p) * G::N;
+    if (*violations != 0) { slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p); return; }   // see k_ntt_fwd_x
     const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
     const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
         out_of_range |= raw >= limit;
         f[r] = hxf::reduce(hxf::to_f64(raw), m);
     }
-    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);
-    const bool slow = __syncthreads_or(out_of_range) || (*violations != 0);      // see k_ntt_fwd_x
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
+    const bool slow = __syncthreads_or(out_of_range);                            // see k_ntt_fwd_x
     if (!slow) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
@@ -182,7 +185,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
     const Mod m{(double)q, 1.0 / (double)q};
-    const bool bad_tables = *violations != 0;
+    if (*violations != 0) {
+        // Tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones): known at kernel entry,
+        // the same for every polynomial and wave-uniform -- the whole batch goes straight through the integer butterflies.
+        // (Rounds 2-3 ran the FP64 transform on every polynomial first and only then fell back: the transform twice.)
+#pragma unroll 1
+        for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+            slow_fwd<LOGN, LOGE>(x + size_t(p) * G::N, lds, roots, precon, q);
+            __syncthreads();
+        }
+        return;
+    }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
     u64 raw[G::E];
     {
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
         WgNttF64<LOGN, LOGE, LAZY>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
-        const bool slow = vote.result(tid) || bad_tables;                        // see k_ntt_fwd_x, RangeVote
+        const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
@@ -231,7 +244,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
     const Mod m{(double)q, 1.0 / (double)q};
-    const bool bad_tables = *violations != 0;
+    if (*violations != 0) {                                                     // see k_ntt_fwd_p
+#pragma unroll 1
+        for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+            slow_inv<LOGN, LOGE>(x + size_t(p) * G::N, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+            __syncthreads();
+        }
+        return;
+    }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
     u64 raw[G::E];
     {
@@ -259,11 +279,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;
         const u64* pnx = x + size_t(pn) * G::N;
         const u32 tB = u32(G::idxB(0, tid));
-        WgNttF64<LOGN, LOGE, LAZY>::template inverse<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, [&] {
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, [&] {   // no w/p table
 #pragma unroll
             for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
         });
-        const bool slow = vote.result(tid) || bad_tables;
+        const bool slow = vote.result(tid);
         if (!slow) {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));

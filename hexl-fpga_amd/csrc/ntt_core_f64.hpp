@@ -24,13 +24,14 @@ typedef const __attribute__((address_space(4))) double* ctw_t;
 // through a ring of TF registers, requested TF sub-blocks ahead, with a scheduling barrier every TF sub-blocks. Left
 // alone the compiler requests all 2^u twiddles of a stage (all 31 of a five-stage pass) up front: ~60 registers that
 // a kernel holding 128 accumulator registers does not have (it spilled a quarter of the accumulators for good).
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0>
+// SHIFT: phase of the reduction schedule (f64_arith.hpp lazy_fwd_reduce_after; 1 = un-centred inputs taken as they are)
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0, int SHIFT = 0>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT);
         constexpr int TFR = TF > 0 ? TF : 1;
         const bool ring = TF > 0 && !UNI && (1 << u) > TF;
         double Wq[TFR];
@@ -59,11 +60,11 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 }
 
 // the same K stages with their 2^K - 1 twiddles already in registers (tw[(1 << u) - 1 + j] = stage u, sub-block j)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0>
 __device__ __forceinline__ void fwd_stages_f64_tw(double (&v)[E], const double (&tw)[(1 << K) - 1], const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = tw[(1 << u) - 1 + j];
@@ -81,7 +82,7 @@ __device__ __forceinline__ void fwd_stages_f64_tw(double (&v)[E], const double (
 // where the compiler puts them: one exposed wait instead of K - 1 at the price of 2^K - 2 registers. (Requesting stage
 // u + 2 ahead of the butterflies of stage u as well -- two stages' twiddles live -- spilled 24-36 registers in the
 // keyswitch kernels: 179 k against 200 k keyswitch/s.)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0>
 __device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, const double* __restrict__ w, const Mod m) {
     double tw[(1 << (K - 1)) - 1];
 #pragma unroll
@@ -91,7 +92,7 @@ __device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, cons
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3);
+        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = u + 1 < K ? tw[(1 << u) - 1 + j] : w[(1u << (S0 - 1 + u)) + (G << u) + j];
@@ -107,7 +108,19 @@ __device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, cons
 
 using hxf::InvScale;
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, int TF = 0>
+// one inverse butterfly of global stage `gs` (1-based); NOWP: no w/p table (f64_arith.hpp gs_bfly_lazy_nowp)
+template <int LAZY, bool NOWP>
+__device__ __forceinline__ void inv_bfly(double& X, double& Y, double W, double Wp, const Mod m, int gs) {
+    if constexpr (NOWP) {
+        if (LAZY && gs != hxf::INV_NOWP_STRICT_STAGE) hxf::gs_bfly_lazy_nowp(X, Y, W, m);
+        else hxf::gs_bfly_nowp(X, Y, W, m);
+    } else {
+        if (LAZY) hxf::gs_bfly_lazy(X, Y, W, Wp, m);
+        else      hxf::gs_bfly(X, Y, W, Wp, m);
+    }
+}
+
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, int TF = 0, bool NOWP = false>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -120,24 +133,24 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
         double Wq[TFR], Wpq[TFR];
         if (ring) {
 #pragma unroll
-            for (int j = 0; j < TFR; ++j) { Wq[j] = iw[base + j]; Wpq[j] = iwp[base + j]; }
+            for (int j = 0; j < TFR; ++j) { Wq[j] = iw[base + j]; Wpq[j] = NOWP ? 0.0 : iwp[base + j]; }
         }
 #pragma unroll
         for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
             double W = 0, Wp = 0;
             if (ring) {
                 W = Wq[j % TFR]; Wp = Wpq[j % TFR];
-                if (j + TFR < (1 << (K - 1 - u))) { Wq[j % TFR] = iw[base + j + TFR]; Wpq[j % TFR] = iwp[base + j + TFR]; }
+                if (j + TFR < (1 << (K - 1 - u))) { Wq[j % TFR] = iw[base + j + TFR]; if (!NOWP) Wpq[j % TFR] = iwp[base + j + TFR]; }
             } else if (!fused) {
-                W = UNI ? ((ctw_t)iw)[base + j] : iw[base + j]; Wp = UNI ? ((ctw_t)iwp)[base + j] : iwp[base + j];
+                W = UNI ? ((ctw_t)iw)[base + j] : iw[base + j];
+                if (!NOWP) Wp = UNI ? ((ctw_t)iwp)[base + j] : iwp[base + j];
             }
 #pragma unroll
             for (int c = 0; c < (1 << u); ++c) {
                 const int a0 = OFF + (j << (u + 1)) + c;
                 const int a1 = a0 + (1 << u);
                 if (!fused) {
-                    if (LAZY) hxf::gs_bfly_lazy(v[a0], v[a1], W, Wp, m);
-                    else      hxf::gs_bfly(v[a0], v[a1], W, Wp, m);
+                    inv_bfly<LAZY, NOWP>(v[a0], v[a1], W, Wp, m, LO + u + 1);
                 } else {                                   // last stage: scale both outputs by n^-1
                     const double s = v[a0] + v[a1], d = v[a0] - v[a1];
                     v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
@@ -152,19 +165,22 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
 // The same K inverse stages with all their 2^K - 1 twiddle pairs requested before the first butterfly (IPRE, kernels with
 // registers to spare: k_ksx_intt). Left alone the compiler requests each pair right in front of its use and waits for it:
 // up to 15 exposed latencies per per-lane pass.
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool NOWP = false>
 __device__ __forceinline__ void inv_stages_f64_pre(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                    const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
     constexpr int NT = (1 << K) - 1;
-    double tw[NT], twp[NT];
+    double tw[NT], twp[NOWP ? 1 : NT];
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const bool fused = LAST && (u == K - 1);
         const u32 base = N - (N >> (LO + u)) + 1 + (G << (K - 1 - u));
 #pragma unroll
         for (int j = 0; j < (1 << (K - 1 - u)); ++j)
-            if (!fused) { tw[(1 << K) - (1 << (K - u)) + j] = iw[base + j]; twp[(1 << K) - (1 << (K - u)) + j] = iwp[base + j]; }
+            if (!fused) {
+                tw[(1 << K) - (1 << (K - u)) + j] = iw[base + j];
+                if constexpr (!NOWP) twp[(1 << K) - (1 << (K - u)) + j] = iwp[base + j];
+            }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -172,14 +188,15 @@ __device__ __forceinline__ void inv_stages_f64_pre(double (&v)[E], u32 G, const 
         const bool fused = LAST && (u == K - 1);
 #pragma unroll
         for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
-            const double W = fused ? 0.0 : tw[(1 << K) - (1 << (K - u)) + j], Wp = fused ? 0.0 : twp[(1 << K) - (1 << (K - u)) + j];
+            const double W = fused ? 0.0 : tw[(1 << K) - (1 << (K - u)) + j];
+            double Wp = 0.0;
+            if constexpr (!NOWP) Wp = fused ? 0.0 : twp[(1 << K) - (1 << (K - u)) + j];
 #pragma unroll
             for (int c = 0; c < (1 << u); ++c) {
                 const int a0 = OFF + (j << (u + 1)) + c;
                 const int a1 = a0 + (1 << u);
                 if (!fused) {
-                    if (LAZY) hxf::gs_bfly_lazy(v[a0], v[a1], W, Wp, m);
-                    else      hxf::gs_bfly(v[a0], v[a1], W, Wp, m);
+                    inv_bfly<LAZY, NOWP>(v[a0], v[a1], W, Wp, m, LO + u + 1);
                 } else {
                     const double s = v[a0] + v[a1], d = v[a0] - v[a1];
                     v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
@@ -205,7 +222,9 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
 // (194 k -> 200 k keyswitch/s); PRE >= 10: the per-lane full pass requests its early stages' twiddles up front as well
 // (fwd_stages_f64_ahead: -> 202 k). Left alone, a kernel that holds 96 data registers gets every twiddle load of that pass right in
 // front of its first use with an s_waitcnt vmcnt(0) behind it -- eight fully exposed L2 latencies per transform.
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0>
+// FSHIFT: phase of the forward reduction schedule (1: un-centred inputs, f64_arith.hpp); NOWP: inverse transforms without
+// the w/p table
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false>
 struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -227,8 +246,8 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, m);
-            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF>(v, Gp, w, wp, m);
+            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, FSHIFT>(v, Gp, w, m);
+            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
                 constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;
@@ -265,14 +284,14 @@ struct WgNttF64 {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
             // LOGN = 0 tells the stage loop that no stage is the last one
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF>(v, Gbits, w, wp, m);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF, FSHIFT>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }
     template <int GRP, bool FINAL = true>
     __device__ static __forceinline__ void fwd_last_tw(double (&v)[E], const double (&tl)[G::NG][(1 << G::KL) - 1], const Mod m) {
         if constexpr (GRP < G::NG) {
-            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY>(v, tl[GRP], m);
+            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, FSHIFT>(v, tl[GRP], m);
             fwd_last_tw<GRP + 1, FINAL>(v, tl, m);
         }
     }
@@ -292,7 +311,7 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY>(v, Gp, w, wp, m);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, false, 0, FSHIFT>(v, Gp, w, wp, m);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
                 redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
@@ -311,8 +330,8 @@ struct WgNttF64 {
                                                      const Mod m, const InvScale sc) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
-            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY>(v, Gbits, iw, iwp, m, sc);
-            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, false, TF>(v, Gbits, iw, iwp, m, sc);
+            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, NOWP>(v, Gbits, iw, iwp, m, sc);
+            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, false, TF, NOWP>(v, Gbits, iw, iwp, m, sc);
             inv_first<GRP + 1, IPRE>(v, tid, iw, iwp, m, sc);
         }
     }
@@ -331,8 +350,8 @@ struct WgNttF64 {
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             if constexpr (inv_pass_uniform<PASS> && (PASS == 0 || !inv_pass_uniform<(PASS > 0 ? PASS - 1 : 0)>)) before_uniform();
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, LOGN, false, LAZY>(v, Gp, iw, iwp, m, sc);
-            else inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF>(v, Gp, iw, iwp, m, sc);
+            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, LOGN, false, LAZY, NOWP>(v, Gp, iw, iwp, m, sc);
+            else inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF, NOWP>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform);
         }
     }

@@ -210,14 +210,17 @@ void execute(Engine& e, Device& dev, const std::vector<Obj>& run) {
         }
         default: break;
     }
-    if (rc == HEXL_E_RANGE && f.kind == KS) {
-        // a t_target word not below its modulus: outside intel::hexl::KeySwitch's contract (the reference checks nothing and
-        // returns whatever its pipeline makes of it). Like an FPGA_ASSERT (fpga_assert.h:24-38) this is fatal only under
-        // FPGA_DEBUG; otherwise say so once and carry on.
+    if (rc == HEXL_W_RANGE && f.kind == KS) {
+        // the run was computed, but one or more of its objects had a t_target word not below its modulus: outside
+        // intel::hexl::KeySwitch's contract (the reference checks nothing and returns whatever its pipeline makes of it). Like an
+        // FPGA_ASSERT (fpga_assert.h:24-38) this is fatal only under FPGA_DEBUG; otherwise count it, and say so the first time and
+        // every 1000th. (HEXL_E_RANGE -- the HEXL_KS_VALIDATE=1 refusal, nothing was computed -- stays fatal below.)
         if (e.debug) die("KeySwitch: a t_target word is not below its modulus", rc);
-        static std::atomic<bool> said{false};
-        if (!said.exchange(true))
-            std::fprintf(stderr, "[hexl-fpga/mi355x] warning: KeySwitch got a t_target word >= its modulus; the result of that object is unspecified\n");
+        static std::atomic<unsigned long> seen{0};
+        const unsigned long k = ++seen;
+        if (k == 1 || k % 1000 == 0)
+            std::fprintf(stderr, "[hexl-fpga/mi355x] warning: KeySwitch got a t_target word >= its modulus in one or more objects of a run of "
+                                 "%zu (the results of those objects are unspecified); %lu such run(s) so far\n", cnt, k);
         return;
     }
     if (rc) die(kind_name[f.kind], rc);

@@ -27,7 +27,9 @@ extern "C" {
 #define HEXL_E_BADARG   (-1)   /* unsupported n / null pointer / size limit */
 #define HEXL_E_NOKEYS   (-2)   /* hexl_keyswitch before hexl_ks_set_keys */
 #define HEXL_E_NODEVICE (-3)   /* no gfx950 device visible */
-#define HEXL_E_RANGE    (-4)   /* a t_target / result word is not below its modulus (hexl_ks_range_check, HEXL_KS_VALIDATE=1) */
+#define HEXL_E_RANGE    (-4)   /* HEXL_KS_VALIDATE=1: a t_target / result word is not below its modulus; the call was REFUSED, nothing computed */
+#define HEXL_W_RANGE    1      /* status, not an error: the call ran, but the FP64 kernels saw a t_target / result word that is not below its
+                                  modulus (hexl_ks_range_check, hexl_keyswitch_host); the output words of such an object are unspecified */
 
 typedef struct hexl_ctx hexl_ctx;         /* one per GPU: stream + scratch */
 typedef struct hexl_ks_plan hexl_ks_plan; /* keyswitch parameter set: tables + keys on device */
@@ -101,10 +103,12 @@ int hexl_keyswitch(hexl_ks_plan* plan, uint64_t* d_result, const uint64_t* d_t_t
                    size_t batch);
 /* The FP64 kernels (moduli < 2^52) check the precondition above where they convert the words anyway -- one compare per
  * word, no extra pass -- and OR the outcome into a flag of the plan. This call waits for the plan's stream and returns
- * HEXL_E_RANGE if any hexl_keyswitch launched on the plan since the previous check saw a t_target / result word >= its
- * modulus (their output words for that instance are then unspecified), 0 otherwise; it clears the flag. The integer kernels
- * (moduli >= 2^52) do not flag: they replay the reference's lazy arithmetic on whatever words they get.
- * hexl_keyswitch_host() calls it itself and returns its status. */
+ * HEXL_W_RANGE (> 0) if any hexl_keyswitch launched on the plan since the flag was last cleared saw a t_target / result word
+ * >= its modulus (the output words of that instance are then unspecified), 0 otherwise; it clears the flag. The integer
+ * kernels (moduli >= 2^52) do not flag: they replay the reference's lazy arithmetic on whatever words they get.
+ * hexl_keyswitch_host() reports for ITS OWN objects only: it clears the flag when it starts (call hexl_ks_range_check first
+ * if earlier device-pointer launches on the plan matter) and returns HEXL_W_RANGE when one or more objects of the call had
+ * an out-of-range word -- it cannot say which. HEXL_E_RANGE (< 0) is different: the HEXL_KS_VALIDATE=1 refusal, nothing ran. */
 int hexl_ks_range_check(hexl_ks_plan* plan);
 /* Beyond the reference's envelope (the use-case of its combined image,
  * device/dyadic_multiply_keyswitch.cpp:4-5): ciphertext multiply + relinearize in one pass.

@@ -1,6 +1,9 @@
 // bench_cxx_api.cpp -- end-to-end (host pointers, PCIe included) throughput of the reference's public C++ API on
 // libhexl-fpga.so, shaped like benchmark/bench_keyswitch.cpp:113-131 and bench_fwd_ntt.cpp:46-62: one warm-up
 // window, then timed worksize windows. Synthetic in-range data (splitmix). Prints keyswitch/s and NTT/s.
+//   usage: bench_cxx_api [worksize = 256] [L = 6] [ntt = 1|0] [json = 0|1]
+// json = 1 prints one JSON object instead (bench.py's `extra.cxx_api_end_to_end` leg: SURVEY 8d's end-to-end measurement at the
+// batch sizes of benchmark/micro_keyswitch.sh -- these rates include PCIe and the host copies and are never `value`).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -19,6 +22,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 int main(int argc, char** argv) {
     const size_t batch = argc > 1 ? atoi(argv[1]) : 256;
     const uint64_t n = 16384, L = argc > 2 ? atoi(argv[2]) : 6, K = L + 1;
+    const bool with_ntt = argc > 3 ? atoi(argv[3]) != 0 : true, json = argc > 4 && atoi(argv[4]) == 1;
     // the eight 52-bit primes of SURVEY 8c (GeneratePrimes(8, 51, 16384))
     const uint64_t primes[8] = {2251799814045697ull, 2251799814799361ull, 2251799814930433ull, 2251799815094273ull,
                                 2251799815487489ull, 2251799815520257ull, 2251799816273921ull, 2251799816568833ull};
@@ -38,12 +42,28 @@ int main(int argc, char** argv) {
         KeySwitchCompleted();
     };
     window();
-    const int iters = 5;
+    // at least 5 windows and at least ~0.3 s: a lone keyswitch takes a quarter of a millisecond
+    int iters = 5;
     double t0 = now();
     for (int i = 0; i < iters; ++i) window();
     double dt = now() - t0;
+    if (dt < 0.3) {
+        iters = (int)(0.3 / (dt / iters)) + 1;
+        t0 = now();
+        for (int i = 0; i < iters; ++i) window();
+        dt = now() - t0;
+    }
+    if (json)
+        std::printf("{\"worksize\": %zu, \"L\": %lu, \"keyswitch_per_s\": %.1f, \"ms_per_window\": %.4f, \"pcie_GBps\": %.2f, \"windows\": %d",
+                    batch, L, batch * iters / dt, dt / iters * 1e3, batch * iters * 3.0 * L * n * 8 / dt / 1e9, iters);
+    else
     std::printf("C++ API end-to-end keyswitch N=%lu L=%lu K=%lu batch=%zu: %.0f keyswitch/s (%.2f ms/window, %.2f GB/s over PCIe)\n",
                 n, L, K, batch, batch * iters / dt, dt / iters * 1e3, batch * iters * 3.0 * L * n * 8 / dt / 1e9);
+    if (!with_ntt) {
+        if (json) std::printf("}\n");
+        release_FPGA_resources();
+        return 0;
+    }
     // NTT: 4096 polynomials, one modulus (bench_fwd_ntt.cpp shape), proper tables not needed for timing
     const size_t ws = 4096;
     vec x(ws * n), roots(n), precon(n);
@@ -58,6 +78,9 @@ int main(int argc, char** argv) {
     t0 = now();
     for (int i = 0; i < 3; ++i) ntt_window();
     dt = now() - t0;
+    if (json)
+        std::printf(", \"ntt_worksize\": %zu, \"fwd_ntt_per_s\": %.1f, \"ntt_pcie_GBps\": %.2f}\n", ws, ws * 3 / dt, ws * 3 * 2.0 * n * 8 / dt / 1e9);
+    else
     std::printf("C++ API end-to-end fwd NTT N=%lu ws=%zu: %.0f NTT/s (%.2f ms/window, %.2f GB/s over PCIe)\n", n, ws, ws * 3 / dt,
                 dt / 3 * 1e3, ws * 3 * 2.0 * n * 8 / dt / 1e9);
     release_FPGA_resources();

@@ -55,6 +55,7 @@ static void test_prime(uint64_t p) {
         // conversions
         uint64_t v = rnd() % p;
         CHECK(hxf::from_f64(hxf::to_f64(v)) == v, "convert %lu", v);
+        CHECK(hxf::to_f64_lt52(v) == hxf::to_f64(v), "convert (OR form) %lu", v);
     }
 }
 
@@ -215,6 +216,122 @@ static void test_transforms_lazy(uint64_t n, uint64_t p, bool adversarial, int p
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "lazy inv n=%lu p=%lu i=%lu", n, p, i);
 }
 
+// ---- round 4 ---------------------------------------------------------------------------------------------------
+// (1) forward transform on the SHIFTED schedule with inputs that are not centred: canonical residues of a neighbouring modulus,
+//     0 <= x < rho p (keyswitch_x.hip SKIP kernels), without the reduction after the last stage, followed by mac_fold;
+// (2) the mod-down epilogue with un-reduced accumulators: mul_shoup(acc - w) at |acc| = 1.7p, |w| up to the tail bound;
+// (3) inverse transforms without the w/p table (gs_bfly_lazy_nowp + the strict stage), canonical inputs taken as they are.
+static void test_round4(uint64_t n, uint64_t p, int period, double rho, bool adversarial) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    int logn = 0; while ((1ull << logn) < n) ++logn;
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t* roots = blk.data() + 2 * n;
+    auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+    const uint64_t top = (uint64_t)(rho * (double)p) - 1;              // inputs in [0, rho p)
+    std::vector<uint64_t> x(n), ref(n);
+    for (uint64_t i = 0; i < n; ++i) x[i] = adversarial ? top - (i & 3) : rnd() % (top + 1);
+    for (uint64_t i = 0; i < n; ++i) ref[i] = x[i] % p;
+    orc_ks_ntt(ref.data(), n, p, roots);
+    std::vector<double> u(n);
+    for (uint64_t i = 0; i < n; ++i) u[i] = hxf::to_f64(x[i]);            // as they are
+    int s = 1;
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
+        const bool red = hxf::lazy_fwd_reduce_after(s, 0, period, 1);
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (red) hxf::ct_bfly(u[j], u[j + t], w, m); else hxf::ct_bfly_lazy(u[j], u[j + t], w, m);
+                track(u[j]); track(u[j + t]);
+            }
+        }
+    }
+    std::vector<uint64_t> key(n);
+    orc_fill_splitmix(key.data(), n, p ^ 0x4444, p);
+    for (uint64_t i = 0; i < n; ++i) {
+        CHECK(hxf::from_f64(hxf::lift(hxf::reduce(u[i], m), m)) == ref[i], "shifted fwd n=%lu p=%lu i=%lu", n, p, i);
+        // mac_fold on the un-reduced output, accumulator at its bound with the sign that pushes outwards
+        const uint64_t kv = adversarial ? ((i & 1) ? p / 2 : p / 2 + 1) : key[i];
+        const double kc = centre(kv);
+        const double acc0 = ((u[i] < 0) != (kc < 0) ? -1.0 : 1.0) * (double)(uint64_t)(1.6 * (double)p);
+        const double acc = hxf::mac_fold(acc0, u[i], kc, m);
+        track(acc);
+        const i128 exact = (i128)(int64_t)acc0 + (i128)(int64_t)u[i] * (int64_t)kc;
+        CHECK(acc == (double)(int64_t)acc && centred(exact - (int64_t)acc, (int64_t)p) == 0 && (acc < 0 ? -acc : acc) <= 1.7 * (double)p,
+              "mac_fold on shifted tail n=%lu p=%lu i=%lu acc=%.0f", n, p, i, acc);
+        // mod-down epilogue: (acc - w) * msf with |acc| = 1.7p un-reduced and w = this un-reduced value (>= the real tail bound)
+        if (period == 3 || (u[i] < 0 ? -u[i] : u[i]) <= 2.2 * (double)p) {
+            const double a17 = (u[i] < 0 ? 1.0 : -1.0) * (double)(uint64_t)(1.7 * (double)p);
+            const double wv = (u[i] < 0 ? -u[i] : u[i]) <= 2.2 * (double)p ? u[i] : (u[i] < 0 ? -1.0 : 1.0) * (double)(uint64_t)(2.2 * (double)p);
+            const uint64_t msf = adversarial ? p / 2 + 1 : key[(i + 1) % n];
+            const double msf_c = centre(msf), in = a17 - wv;
+            const double out = hxf::mul_shoup(in, msf_c, msf_c / (double)p, m);
+            track(in); track(out);
+            CHECK(out == (double)(int64_t)out && centred((i128)(int64_t)in * (int64_t)msf_c - (int64_t)out, (int64_t)p) == 0,
+                  "moddown on un-reduced acc n=%lu p=%lu i=%lu", n, p, i);
+        }
+    }
+    // centred s' (|y| <= rho p / 2) straight into the standard schedule
+    for (uint64_t i = 0; i < n; ++i) {
+        const int64_t y = adversarial ? ((i & 1) ? 1 : -1) * (int64_t)(top / 2) : (int64_t)(rnd() % (top + 1)) - (int64_t)(top / 2);
+        u[i] = (double)y;
+        ref[i] = (uint64_t)centred((i128)y, (int64_t)p);
+    }
+    orc_ks_ntt(ref.data(), n, p, roots);
+    s = 1;
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
+        const bool red = hxf::lazy_fwd_reduce_after(s, 0, period, 0);
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (red) hxf::ct_bfly(u[j], u[j + t], w, m); else hxf::ct_bfly_lazy(u[j], u[j + t], w, m);
+                track(u[j]); track(u[j + t]);
+            }
+        }
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(hxf::reduce(u[i], m), m)) == ref[i], "centred s' fwd n=%lu p=%lu i=%lu", n, p, i);
+}
+
+// inverse without the w/p table, canonical input words as they are; lazy = the lazy kernels' schedule, else the strict one
+static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversarial) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t* inv0 = blk.data();
+    auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+    std::vector<uint64_t> x(n), ref;
+    orc_fill_splitmix(x.data(), n, p ^ (n + 99), p);
+    if (adversarial) for (uint64_t i = 0; i < n; ++i) x[i] = (i & 1) ? p - 1 : ((i & 2) ? 0 : p - 2);
+    ref = x; orc_ks_intt(ref.data(), n, p, inv0);
+    std::vector<double> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = hxf::to_f64_lt52(x[i]);
+    const double ninv = centre(orc_invmod(n, p)), ninv_p = ninv / (double)p;
+    const double nw = centre(orc_mulmod(orc_invmod(n, p), inv0[n - 2], p)), nw_p = nw / (double)p;
+    uint64_t acc = 0;
+    int gs = 1;
+    for (uint64_t mm = n >> 1, t = 1; mm >= 1; mm >>= 1, t <<= 1, ++gs) {
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(inv0[acc + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (mm > 1) {
+                    const double dd = v[j] - v[j + t];
+                    track(dd); track(v[j] + v[j + t]);
+                    if (lazy && gs != hxf::INV_NOWP_STRICT_STAGE) hxf::gs_bfly_lazy_nowp(v[j], v[j + t], w, m);
+                    else hxf::gs_bfly_nowp(v[j], v[j + t], w, m);
+                } else {
+                    const double sum = v[j] + v[j + t], dif = v[j] - v[j + t];
+                    track(sum); track(dif);
+                    v[j] = hxf::reduce(hxf::mul_shoup(sum, ninv, ninv_p, m), m);
+                    v[j + t] = hxf::reduce(hxf::mul_shoup(dif, nw, nw_p, m), m);
+                }
+                track(v[j]); track(v[j + t]);
+            }
+        }
+        acc += mm;
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "nowp inverse n=%lu p=%lu lazy=%d i=%lu", n, p, (int)lazy, i);
+}
+
 int main() {
     std::vector<uint64_t> primes;
     uint64_t tmp[8];
@@ -240,7 +357,14 @@ int main() {
             CHECK((double)p <= hxf::LAZY_MAX_MODULUS, "prime %lu not lazy-admissible", p);
             for (uint64_t n : {1024ull, 2048ull, 16384ull}) { test_transforms_lazy(n, p, false); test_transforms_lazy(n, p, true); }
         }
-        for (uint64_t p : primes) if ((double)p <= hxf::LAZY_MAX_MODULUS) test_mac_fold(p, 2.14);
+        for (uint64_t p : primes) if ((double)p <= hxf::LAZY_MAX_MODULUS) { test_mac_fold(p, 2.14); test_mac_fold(p, 3.46); }
+        // round 4: shifted schedule / un-reduced accumulators / table-free inverse, at the ratio bound and at equal-sized moduli
+        for (uint64_t p : lazy_primes)
+            for (uint64_t n : {1024ull, 2048ull, 4096ull, 8192ull, 16384ull})
+                for (int adv = 0; adv < 2; ++adv) {
+                    if ((double)p > (double)(1ull << 50)) { test_round4(n, p, 3, hxf::LAZY_SKIP_MAX_RATIO, adv); test_round4(n, p, 3, 1.008, adv); }
+                    test_inverse_nowp(n, p, true, adv);
+                }
         std::printf("lazy schedules: max |x| seen = 2^%.3f (limit 2^53)\n", log2(g_max_abs));
         CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded");
         // longer reduction periods for smaller moduli (f64_arith.hpp: lazy_period_for): the largest admissible prime
@@ -257,10 +381,17 @@ int main() {
                 for (uint64_t n : {1024ull, 16384ull}) { test_transforms_lazy(n, p, false, period); test_transforms_lazy(n, p, true, period); }
             }
             for (uint64_t p : tp) test_mac_fold(p, tier == 0 ? 4.82 : 9.5);      // two un-reduced tail stages after a reduction
+            for (uint64_t p : tp) test_mac_fold(p, tier == 0 ? 6.3 : 11.9);      // a whole period un-reduced (shifted schedule)
+            for (uint64_t p : tp)
+                for (uint64_t n : {1024ull, 16384ull})
+                    for (int adv = 0; adv < 2; ++adv) { test_round4(n, p, period, hxf::LAZY_SKIP_MAX_RATIO, adv); test_inverse_nowp(n, p, true, adv); }
             std::printf("period %2d (p <= 2^%d): max |x| seen = 2^%.3f (limit 2^53)\n", period, tier == 0 ? 50 : 49, log2(g_max_abs));
             CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded for period %d", period);
         }
     }
+    // strict kernels (moduli up to 2^52): table-free inverse with both outputs reduced
+    for (uint64_t p : primes)
+        for (uint64_t n : {1024ull, 16384ull}) { test_inverse_nowp(n, p, false, false); test_inverse_nowp(n, p, false, true); }
     std::printf("folded multiply-accumulate: max |acc| / p seen = %.3f (bound 1.6)\n", g_fold_max);
     std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());
     return failures ? 1 : 0;

@@ -42,3 +42,15 @@ def test_power_sampler_without_hwmon_is_silent():
     s.dir = None                                                    # a box without the amdgpu hwmon files
     s.start()
     assert s.stop() is None
+
+
+def test_alu_fraction_uses_the_timed_regions_clock():
+    """round 3's 0.698 divided un-profiled time by the PMC passes' clock; the timed region's own clock gives 0.66 (VERDICT r03 #3)"""
+    import bench
+    vw, cus, us = 1_811_296, 256, 4.966                                  # BENCH_r03: instructions / keyswitch, measured us / keyswitch
+    a = bench.alu_block(vw, cus, us, timed_sclk_mhz=2153.0, pmc_clock_ghz=2.042)
+    assert abs(a["issue_us_per_keyswitch"] - vw * 4 / 1024 / 2153.0) < 1e-12
+    assert abs(a["achieved_frac"] - 0.6617) < 5e-4 and abs(a["achieved_frac_at_pmc_pass_clock"] - 0.6977) < 5e-4
+    assert a["achieved_frac"] < a["achieved_frac_at_pmc_pass_clock"] and a["shader_clock_ghz"] == 2.153
+    b = bench.alu_block(vw, cus, us, timed_sclk_mhz=None, pmc_clock_ghz=2.042)   # no hwmon: falls back, and says so
+    assert b["achieved_frac"] == b["achieved_frac_at_pmc_pass_clock"] and "PMC" in b["shader_clock_source"]

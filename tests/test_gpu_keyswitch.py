@@ -317,6 +317,66 @@ except hx.HexlError as e:
     assert out.returncode == 0 and "REJECTED True True" in out.stdout
 
 
+def test_validation_on_the_host_pointer_path():
+    """HEXL_KS_VALIDATE=1 through hexl_keyswitch_host at worksize 1: small sub-batches WRITE their device-side result
+    buffer, which is uninitialised on purpose -- the validation must look at t_target only there, accept in-range inputs and compute;
+    an out-of-range t_target word is still refused (HEXL_E_RANGE = -4, nothing computed)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+from ks_util import KsCase
+ctx = hx.Context(0)
+case = KsCase(orc, 4096, 3, 4, seed=9)
+plan = hx.KeySwitchPlan(ctx, 4096, 3, 4, 4, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
+for rep in range(3):                                            # the staging buffer holds the previous call's output by then
+    t, r = case.inputs(orc, rep)
+    got = r.copy()
+    assert plan.keyswitch_host([got], [t]) is True
+    assert np.array_equal(got, case.expected(orc, t, r)), rep
+bad = t.copy(); bad[4096 + 17] = case.moduli[1]
+r2 = r.copy()
+try:
+    plan.keyswitch_host([r2], [bad])
+    print("NOT REJECTED")
+except hx.HexlError as e:
+    print("REJECTED", "-4" in str(e), bool(np.array_equal(r2, r)))
+''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HEXL_KS_VALIDATE="1"))
+    print(out.stdout[-1000:], out.stderr[-1500:])
+    assert out.returncode == 0 and "REJECTED True True" in out.stdout
+
+
+def test_host_pointer_range_status_covers_its_own_call(hx, ctx, dev, orc):
+    """hexl_keyswitch_host returns HEXL_W_RANGE (computed, but an object had a word >= its modulus) for ITS objects only: a flag
+    an earlier device-pointer launch left on the plan does not leak into a clean host call (ADVICE r03), a dirty host call reports
+    and still computes the clean objects of the run, and the next clean call is clean again"""
+    n, L, K = 4096, 3, 4
+    case = KsCase(orc, n, L, K, seed=14)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    t, r = case.inputs(orc, 0)
+    bad = t.copy()
+    bad[2 * n + 5] = case.moduli[2]
+    d_t, d_r = hx.as_i64(bad).to(dev), hx.as_i64(r).to(dev)
+    plan.keyswitch(d_r, d_t, 1)                                   # leaves the plan's flag set, nobody reads it
+    ctx.sync()
+    got = r.copy()
+    assert plan.keyswitch_host([got], [t]) is True                # clean call: clean status
+    assert np.array_equal(got, case.expected(orc, t, r))
+    t1, r1 = case.inputs(orc, 1)
+    g0, g1 = r.copy(), r1.copy()
+    assert plan.keyswitch_host([g0, g1], [bad, t1]) is False      # dirty object 0, clean object 1
+    assert np.array_equal(g1, case.expected(orc, t1, r1))
+    got = r.copy()
+    assert plan.keyswitch_host([got], [t]) is True
+    plan.close()
+
+
 @pytest.mark.parametrize("nb", [1, 96, 600])
 def test_range_flag_of_the_fp64_kernels(hx, ctx, dev, orc, nb):
     """the FP64 kernels check their precondition (every word below its modulus) where they convert the words: a single
@@ -369,7 +429,32 @@ def test_bd_major_pipeline_on_small_rings(n, nb):
     _alternative({"HEXL_KS_PIPE": "1"}, n, 3, 4, nb)
 
 
-def _alternative(env, n, L, K, nb):
+# Round 4: the slot-major kernels (HEXL_KS_PIPE=3 forces them for every batch) in every arithmetic tier and in both variants of the
+# lazy kernels -- SKIP (moduli within a factor 1.25 of each other: c_d and s' enter the transforms without a range reduction, on the
+# shifted schedule) and non-SKIP (HEXL_KSX_SKIP=0, or moduli of different sizes) -- plus the strict kernels. Rounds 1-3 covered the
+# tiers below 2^51 with two instances only, i.e. on the (b, d)-major kernels.
+TIERS = {
+    "skip_period3_51bit": ({}, "None"),
+    "noskip_forced_period3_51bit": ({"HEXL_KSX_SKIP": "0"}, "None"),
+    "skip_period3_ratio_1p24": ({}, "[orc.primes(1, 51, n)[0]] + primes_below(orc, K - 1, int(0.81 * 2**51), n)"),
+    "skip_period3_special_prime_smallest": ({}, "orc.primes(K - 1, 51, n) + primes_below(orc, 1, int(0.81 * 2**51), n)"),
+    "skip_period6_just_below_2^50": ({}, "primes_below(orc, K, 1 << 50, n)"),
+    "skip_period12_just_below_2^49": ({}, "primes_below(orc, K, 1 << 49, n)"),
+    "noskip_period6_mixed_50_to_40bit": ({}, "primes_below(orc, 2, 1 << 50, n) + orc.primes(K - 3, 40, n) + orc.primes(1, 45, n)"),
+    "noskip_period3_mixed_51_and_30bit": ({}, "orc.primes(2, 51, n)[:1] + orc.primes(K - 2, 30, n) + orc.primes(2, 51, n)[1:]"),
+    "strict_just_below_2^52": ({}, "primes_below(orc, K, 1 << 52, n)"),
+    "strict_forced_51bit": ({"HEXL_KS_NOLAZY": "1"}, "None"),
+}
+
+
+@pytest.mark.parametrize("tier", list(TIERS))
+@pytest.mark.parametrize("n,L,K,nb", [(16384, 6, 7, 70), (16384, 3, 4, 300), (2048, 3, 4, 40)])
+def test_slot_major_kernels_in_every_tier(tier, n, L, K, nb):
+    env, moduli = TIERS[tier]
+    _alternative(dict(env, HEXL_KS_PIPE="3"), n, L, K, nb, moduli)
+
+
+def _alternative(env, n, L, K, nb, moduli="None"):
     """`nb` instances (three distinct ones repeated) through the library in a child process with `env` set, against the oracle"""
     import os
     import subprocess
@@ -378,10 +463,10 @@ def _alternative(env, n, L, K, nb):
 import sys
 sys.path[:0] = [%r, %r, %r]
 import numpy as np, torch, hexl_fpga_amd as hx, orc
-from ks_util import KsCase
+from ks_util import KsCase, primes_below
 dev = torch.device("cuda:0"); ctx = hx.Context(0)
 n, L, K, nb = %d, %d, %d, %d
-case = KsCase(orc, n, L, K, seed=77)
+case = KsCase(orc, n, L, K, seed=77, moduli=%s)
 plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
 ins = [case.inputs(orc, b) for b in range(3)]
 d_t = hx.as_i64(np.concatenate([ins[b %% 3][0] for b in range(nb)])).to(dev)
@@ -390,7 +475,7 @@ plan.keyswitch(d_r, d_t, nb); ctx.sync()
 out = hx.to_u64(d_r).reshape(nb, -1)
 want = [case.expected(orc, t, r) for t, r in ins]
 print("OK" if all(np.array_equal(out[b], want[b %% 3]) for b in range(nb)) else "MISMATCH")
-''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"), n, L, K, nb)
+''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"), n, L, K, nb, moduli)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     print(out.stdout[-500:], out.stderr[-1500:])
     assert out.returncode == 0 and out.stdout.strip().endswith("OK")

@@ -89,6 +89,61 @@ def test_random_tables_like_benchmark(hx, ctx, dev, orc):
     assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t))
 
 
+def test_reference_benchmark_workload_takes_the_integer_path_once(orc):
+    """benchmark/bench_fwd_ntt.cpp:25-42 / bench_inv_ntt.cpp: q = 136314881 (< 2^52, so the FP64 fast-path kernels are launched) with
+    RANDOM roots / precons / inv_n / inv_n_w: the tables fail the device-side Shoup check, which is known at kernel entry -- the
+    kernels must go straight to the integer butterflies (rounds 2-3 ran the FP64 transform first and then fell back: the transform
+    twice). Bit-exact against the oracle, and not slower than the integer-only kernels (HEXL_NTT_INT=1) on the same data."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys, json
+sys.path[:0] = [%r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+dev = torch.device("cuda:0"); ctx = hx.Context(0)
+n, q, batch = 16384, 136314881, 1024
+rng = np.random.default_rng(5)
+t = orc.HexlTables(n, q)
+for arr in (t.roots, t.precon, t.inv_roots, t.inv_precon):
+    arr[:] = rng.integers(0, q, size=n, dtype=np.uint64)
+t.inv_n, t.inv_n_w = int(rng.integers(0, q)), int(rng.integers(0, q))
+x = rng.integers(0, q, size=(8, n), dtype=np.uint64)
+d = hx.as_i64(np.tile(x, (batch // 8, 1)).reshape(-1)).to(dev)
+tabs = [hx.as_i64(a).to(dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
+res = {}
+for name in ("fwd", "inv"):
+    run = (lambda: ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)) if name == "fwd" else (lambda: ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n))
+    d0 = d.clone()
+    run(); ctx.sync()
+    got = hx.to_u64(d).reshape(batch, n)
+    want = orc.ntt_fwd(x, t) if name == "fwd" else orc.ntt_inv(x, t)
+    res[name + "_exact"] = bool(np.array_equal(got[:8], want) and np.array_equal(got[-8:], want))
+    d.copy_(d0)
+    for _ in range(20): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100): run()
+    e1.record(); torch.cuda.synchronize()
+    res[name + "_ms"] = e0.elapsed_time(e1) / 100
+print("RESULT", json.dumps(res))
+''' % (str(root), str(root / "oracle"))
+    out = {}
+    for label, env in (("default", {}), ("integer_only", {"HEXL_NTT_INT": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and line, r.stderr[-1500:]
+        out[label] = json.loads(line[-1][7:])
+    print(out)
+    for name in ("fwd", "inv"):
+        assert out["default"][name + "_exact"] and out["integer_only"][name + "_exact"], name
+        assert out["default"][name + "_ms"] <= 1.15 * out["integer_only"][name + "_ms"], (name, out)
+
+
 def test_full_batch_roundtrip_and_linearity(hx, ctx, dev, orc):
     """BASELINE config 2: fwd+inv NTT, N=16384, batch=1024 -- size-independent properties"""
     import torch

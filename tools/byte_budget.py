@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""byte_budget.py -- where the keyswitch pipeline's bytes and watts go, by STREAM.
+
+Runs on the GPU box (rocprofv3 + the profiling build of the library):
+
+  1. counter passes of tools/pmc_workload_prof (two launches of one 256-keyswitch chunk) for every stream-aliasing mask of
+     HEXL_KSX_ALIAS (keyswitch_x.hip: 1 keys, 2 c / s' reads, 4 t_target reads, 8 result read-modify-write, 16 twiddle tables;
+     0 = the real pipeline): CU-side requests (TCP_TCC_READ_REQ / WRITE_REQ: what the vector L1s ask the L2 for), L2 requests and
+     hits (TCC_REQ / HIT / MISS), fabric-side bytes (FETCH_SIZE x 2, WRITE_SIZE: the gfx950 corrections of MI355X_MICROARCH.md),
+     and for mask 0 the instruction mix (LDS / vector-memory / scalar-memory instructions, LDS bank conflicts).
+     One counter group per run, --kernel-trace only (no other trace domains), as the guide prescribes.
+  2. a power leg per mask: the same workload looping ~8 s with the board power and shader clock sampled from hwmon
+     (HEXL_WORKLOAD_POWER=1) -> keyswitch/s, W, MHz, mJ per keyswitch. Aliasing a stream onto one row makes it an L2 / L1 hit:
+     what the throughput and the energy per keyswitch do then is that stream's share of the watts.
+  3. a calibration of bytes per TCP_TCC_READ_REQ / TCC_REQ on a known byte count (tools/fetch_calib: 1 GiB per kernel, cache-cold).
+
+Writes <out>/r04_bytes.json (default gpurun_out/bytes/) -- copy to profiles/r04_bytes.json.
+
+    python tools/byte_budget.py [--out DIR] [--L 7] [--power-seconds 8] [--masks 0,1,2,4,8,16,31]
+"""
+import argparse
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+N = 16384
+STREAM = {0: "none (the real pipeline)", 1: "key rows", 2: "c and s' reads", 4: "t_target reads", 8: "result read-modify-write",
+          16: "twiddle tables", 31: "all five streams"}
+GROUPS = {
+    "tcp": "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum",
+    "tcc": "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum",
+    "fetch": "FETCH_SIZE",
+    "write": "WRITE_SIZE",
+    "sq": "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE",
+}
+
+
+def rocprof():
+    import shutil
+    return shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+
+
+def run_pass(out_dir, counters, cmd, env, timeout=180):
+    r = subprocess.run([rocprof(), "--kernel-trace", "--pmc", *counters.split(), "-d", str(out_dir), "--", *cmd],
+                       cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode:
+        raise RuntimeError(f"rocprofv3 '{counters}' exited {r.returncode}: {r.stderr[-300:]}")
+    vals, dur = {}, {}
+    for db in glob.glob(f"{out_dir}/**/*.db", recursive=True):
+        cur = sqlite3.connect(db).cursor()
+        for name, cname, avg in cur.execute("select kernel_name, counter_name, avg(value) from counters_collection group by kernel_name, counter_name"):
+            k = name.split("(")[0].replace("void ", "")
+            vals.setdefault(k, {})[cname] = avg
+        for name, avg in cur.execute("select name, avg(end-start) from kernels group by name"):
+            dur[name.split("(")[0].replace("void ", "")] = avg / 1e3
+    return vals, dur
+
+
+def short(k):
+    return k.split("<")[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "bytes"))
+    ap.add_argument("--L", type=int, default=7)
+    ap.add_argument("--power-seconds", type=float, default=8.0)
+    ap.add_argument("--masks", default="0,1,2,4,8,16,31")
+    ap.add_argument("--rate-guess", type=float, default=200e3, help="keyswitch/s used to size the power legs")
+    a = ap.parse_args()
+    out = Path(a.out)
+    out.mkdir(parents=True, exist_ok=True)
+    exe = ROOT / "tools" / "pmc_workload_prof"
+    assert exe.exists(), "tools/pmc_workload_prof not built (make -C tools)"
+    env0 = dict(os.environ, TMPDIR="/tmp", HEXL_KS_ONE_LANE="1")
+    masks = [int(m) for m in a.masks.split(",")]
+    batch, L = 256, a.L
+    res = {"N": N, "L": L, "chunk": batch, "alg_bytes_per_keyswitch": 5 * L * N * 8, "masks": {}, "stream_of_mask": {str(k): v for k, v in STREAM.items()},
+           "units": "bytes and requests PER KEYSWITCH (per-dispatch averages of one 256-keyswitch chunk / 256), summed over the pipeline's three kernels "
+                    "unless under `per_kernel`"}
+
+    # 3. calibration: bytes per request on known byte counts
+    calib = {}
+    fc = ROOT / "tools" / "fetch_calib"
+    if fc.exists():
+        for grp in ("tcp", "tcc", "fetch"):
+            try:
+                vals, _ = run_pass(out / f"calib_{grp}", GROUPS[grp], [str(fc)], env0)
+                calib[grp] = {short(k): v for k, v in vals.items() if k.startswith("k_")}
+            except Exception as e:
+                calib[grp] = {"error": str(e)[:200]}
+        res["calibration_1GiB_per_kernel"] = calib
+    gib = float(1 << 30)
+
+    def per_req(grp, kernel, counter):
+        try:
+            return gib / calib[grp][kernel][counter]
+        except Exception:
+            return None
+    # 8-byte-per-lane coalesced reads are the pipeline's dominant access shape (A order; B order is the 32-byte-stride variant)
+    b_tcp_rd = per_req("tcp", "k_read8", "TCP_TCC_READ_REQ_sum") or 64.0
+    b_tcp_wr = per_req("tcp", "k_write8", "TCP_TCC_WRITE_REQ_sum") or 64.0
+    b_tcc = per_req("tcc", "k_read8", "TCC_REQ_sum") or 128.0
+    res["bytes_per_request"] = {"TCP_TCC_READ_REQ": b_tcp_rd, "TCP_TCC_WRITE_REQ": b_tcp_wr, "TCC_REQ": b_tcc,
+                                "note": "1 GiB / requests of the 8-byte-per-lane coalesced calibration kernels; 64 / 64 / 128 assumed where a pass failed"}
+
+    for m in masks:
+        env = dict(env0, HEXL_KSX_ALIAS=str(m))
+        e = {"stream_aliased": STREAM.get(m, f"mask {m}"), "per_kernel": {}}
+        groups = ["tcp", "tcc", "fetch", "write"] + (["sq"] if m == 0 else [])
+        allv, alld = {}, {}
+        for grp in groups:
+            try:
+                vals, dur = run_pass(out / f"m{m}_{grp}", GROUPS[grp], [str(exe), str(batch), str(L), "2"], env)
+            except Exception as ex:
+                e.setdefault("errors", []).append(str(ex)[:200])
+                continue
+            for k, v in vals.items():
+                if k.startswith("k_ks"):
+                    allv.setdefault(k, {}).update(v)
+                    alld.setdefault(k, []).append(dur.get(k, 0.0))
+        tot = {}
+        for k, v in allv.items():
+            pk = {"avg_us_under_pmc": sum(alld[k]) / len(alld[k])}
+            if "TCP_TCC_READ_REQ_sum" in v:
+                pk["cu_side_read_bytes"] = v["TCP_TCC_READ_REQ_sum"] * b_tcp_rd / batch
+                pk["cu_side_write_bytes"] = v["TCP_TCC_WRITE_REQ_sum"] * b_tcp_wr / batch
+                pk["l1_accesses"] = v.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / batch
+            if "TCC_REQ_sum" in v:
+                pk["l2_requests"] = v["TCC_REQ_sum"] / batch
+                pk["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+            if "FETCH_SIZE" in v:
+                pk["fabric_read_bytes"] = v["FETCH_SIZE"] * 1024 * 2 / batch
+            if "WRITE_SIZE" in v:
+                pk["fabric_write_bytes"] = v["WRITE_SIZE"] * 1024 / batch
+            for c in ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+                      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+                if c in v:
+                    pk[c.lower() + "_per_keyswitch"] = v[c] / batch
+            if "SQ_INSTS_LDS" in v:
+                # every LDS instruction of these kernels moves one 8-byte word per lane: 512 B per wave-instruction
+                pk["lds_bytes"] = v["SQ_INSTS_LDS"] * 512 / batch
+            e["per_kernel"][k] = pk
+            for kk, vv in pk.items():
+                if kk.endswith("_bytes") or kk in ("l2_requests", "l1_accesses"):
+                    tot[kk] = tot.get(kk, 0.0) + vv
+        e["pipeline"] = tot
+        # 2. the power leg
+        reps = max(4, int(a.power_seconds * a.rate_guess / 2048))
+        try:
+            r = subprocess.run([str(exe), "2048", str(L), str(reps)], env=dict(env, HEXL_WORKLOAD_POWER="1"), capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            e["power_leg"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as ex:
+            e["power_leg"] = {"error": str(ex)[:200]}
+        res["masks"][str(m)] = e
+        print(f"mask {m:2d} ({e['stream_aliased']}): " + json.dumps({**{k: round(v / 1e6, 3) for k, v in tot.items() if k.endswith('_bytes')},
+                                                                     **{k: e['power_leg'].get(k) for k in ('keyswitch_per_s', 'board_power_w_mean', 'sclk_mhz_mean', 'mj_per_keyswitch')}}), flush=True)
+
+    # per-stream shares: (real pipeline) - (that stream aliased)
+    base = res["masks"].get("0", {})
+    if base.get("pipeline"):
+        shares = {}
+        for m in masks:
+            if m == 0 or str(m) not in res["masks"] or not res["masks"][str(m)].get("pipeline"):
+                continue
+            al = res["masks"][str(m)]
+            s = {k: base["pipeline"].get(k, 0.0) - al["pipeline"].get(k, 0.0) for k in ("cu_side_read_bytes", "fabric_read_bytes", "fabric_write_bytes")}
+            bp, ap_ = base.get("power_leg", {}), al.get("power_leg", {})
+            if bp.get("mj_per_keyswitch") and ap_.get("mj_per_keyswitch"):
+                s["mj_per_keyswitch_saved_when_aliased"] = bp["mj_per_keyswitch"] - ap_["mj_per_keyswitch"]
+                s["throughput_gain_when_aliased"] = ap_["keyswitch_per_s"] / bp["keyswitch_per_s"] - 1.0
+                s["sclk_mhz_when_aliased"] = ap_["sclk_mhz_mean"]
+            shares[STREAM.get(m, str(m))] = s
+        res["stream_shares"] = shares
+        res["stream_shares_note"] = ("bytes: what leaves the counters when a stream reads one row (its L2-miss-side share; the CU-side requests stay, they "
+                                     "only hit); energy / throughput: what the pipeline gains when that stream costs (almost) nothing -- an upper bound on what "
+                                     "any re-layout of that stream can buy")
+    (out / "r04_bytes.json").write_text(json.dumps(res, indent=1))
+    print("wrote", out / "r04_bytes.json")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -4,16 +4,62 @@
 // bench.py can afford to run the PMC passes of its roofline block INSIDE the benchmark run.
 //   usage: pmc_workload <batch> <L> [reps = 2] [ntt = 0|1]
 // Data are synthetic and nothing is checked here: parity is the test suite's job, this only feeds counters.
+// With HEXL_WORKLOAD_POWER=1 the timed keyswitch loop is also sampled for board power and shader clock (amdgpu hwmon, every
+// 50 ms) and one JSON line with keyswitch/s, W, MHz and mJ per keyswitch is printed: tools/byte_budget.py runs that with `reps`
+// large enough for ~8 s per leg, once per stream-aliasing mask of the profiling build (pmc_workload_prof, HEXL_KSX_ALIAS).
 #include <hip/hip_runtime.h>
 
+#include <glob.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/hexl_mi355x.h"
 
 #define CK(e) do { int rc_ = (int)(e); if (rc_) { std::fprintf(stderr, "%s failed: %d\n", #e, rc_); return 1; } } while (0)
+
+// board power / shader clock of the first amdgpu hwmon that reports power (one-GPU boxes), sampled on a thread
+struct PowerProbe {
+    std::string dir;
+    std::atomic<bool> stop{false};
+    std::thread th;
+    double w_sum = 0, f_sum = 0, w_max = 0;
+    long n = 0, nf = 0;
+    static double read(const std::string& f) {
+        FILE* fp = std::fopen(f.c_str(), "r");
+        if (!fp) return -1;
+        double v = -1;
+        if (std::fscanf(fp, "%lf", &v) != 1) v = -1;
+        std::fclose(fp);
+        return v;
+    }
+    PowerProbe() {
+        glob_t g{};
+        if (!::glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", 0, nullptr, &g) && g.gl_pathc) {
+            dir = g.gl_pathv[0];
+            dir = dir.substr(0, dir.rfind('/'));
+        }
+        globfree(&g);
+    }
+    void start() {
+        if (dir.empty()) return;
+        th = std::thread([this] {
+            while (!stop.load()) {
+                const double w = read(dir + "/power1_average"), f = read(dir + "/freq1_input");
+                if (w > 0) { w_sum += w / 1e6; w_max = w / 1e6 > w_max ? w / 1e6 : w_max; ++n; }
+                if (f > 0) { f_sum += f / 1e6; ++nf; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+        });
+    }
+    void finish() { stop = true; if (th.joinable()) th.join(); }
+};
 
 static uint64_t sm_state = 7;
 static uint64_t sm() {
@@ -68,8 +114,21 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dt + have * tw, dt, cnt * tw * 8, hipMemcpyDeviceToDevice));
         CK(hipMemcpy(dr + have * rw, dr, cnt * rw * 8, hipMemcpyDeviceToDevice));
     }
+    const bool power = getenv("HEXL_WORKLOAD_POWER") && atoi(getenv("HEXL_WORKLOAD_POWER")) == 1;
+    if (power) { CK(hexl_keyswitch(plan, dr, dt, batch)); CK(hexl_ctx_sync(ctx)); }      // warm-up: scratch, clocks
+    PowerProbe probe;
+    if (power) probe.start();
+    const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < reps; ++r) CK(hexl_keyswitch(plan, dr, dt, batch));
     CK(hexl_ctx_sync(ctx));
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (power) {
+        probe.finish();
+        const double rate = double(batch) * reps / secs, w = probe.n ? probe.w_sum / probe.n : 0, f = probe.nf ? probe.f_sum / probe.nf : 0;
+        std::printf("{\"keyswitch_per_s\": %.1f, \"seconds\": %.3f, \"batch\": %zu, \"reps\": %d, \"L\": %lu, \"board_power_w_mean\": %.1f, "
+                    "\"board_power_w_max\": %.1f, \"sclk_mhz_mean\": %.1f, \"power_samples\": %ld, \"mj_per_keyswitch\": %.4f}\n",
+                    rate, secs, batch, reps, (unsigned long)L, w, probe.w_max, f, probe.n, rate > 0 ? w / rate * 1e3 : 0.0);
+    }
     if (with_ntt) {
         // tables need not be genuine for counters, but genuine Shoup pairs keep the exact FP64 fast path (ntt.hip) in play
         const uint64_t q = moduli[0], nb = 1024;
