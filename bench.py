@@ -136,52 +136,49 @@ def time_dyadic(hx, ctx, orc_mod, dev, batch=4096, n=8192, nm=4, iters=5):
     return {"ms_per_launch": ms, "items_per_s": batch / (ms * 1e-3), "alg_GBps": batch * 7 * nm * n * 8 / (ms * 1e-3) / 1e9}
 
 
-def cpu_baseline(orc_mod, case, budget_s=10.0):
-    """oracle/cpu_baseline.c (Harvey/Shoup port of the reference's CPU algorithms, built -O3 -march=native on THIS host)
-    timed on the host cores: one thread, then OpenMP over independent ciphertexts on every core the process may use.
-    Bounded sample: ~budget_s seconds per leg. Checked against the line-by-line oracle on one instance first."""
+def cpu_baseline(orc_mod, case, budget_s=24.0):
+    """oracle/cpu_baseline.c (Harvey/Shoup port of the reference's CPU algorithms with the AVX-512 kernels HEXL's rule selects, built
+    -O3 -march=native on THIS host) timed on the host cores with its NUMA-aware leg (cb_keyswitch_timed, round 4): every OpenMP
+    thread pinned to its own core, with a private first-touched copy of its ciphertexts and scratch, and the keys / key Shoup
+    factors / twiddle tables (33 MB) replicated once per NUMA node -- round 3's single copy, first-touched by one thread, fed all
+    128 threads out of one node's memory (3.9 % parallel efficiency). Legs: 1, 16, 64 threads, one per physical core, one per
+    hardware thread; `value` = the best. Bounded sample: ~budget_s seconds in all. Each leg's first keyswitch is checked against
+    the line-by-line oracle."""
     cb = orc_mod.CpuKeySwitch(case.n, case.L, case.K, case.moduli, case.keys, case.modswitch)
     t1, r1 = case.inputs(orc_mod, 0)
+    want = case.expected(orc_mod, t1, r1)
     got = r1.copy()
     cb.keyswitch_batch(got, t1, 1)
-    assert np.array_equal(got, case.expected(orc_mod, t1, r1)), "CPU port disagrees with the oracle"
+    assert np.array_equal(got, want), "CPU port disagrees with the oracle"
     isa = cb.isa()
     cores = len(os.sched_getaffinity(0))
     # omp_get_max_threads() inside this process is the OpenMP runtime torch has already configured: one thread per PHYSICAL core
-    # (128 on the 2 x 64-core, 256-hardware-thread boxes of this pool). Both are timed: one thread per physical core and one per
-    # visible hardware thread; `value` is the better of the two.
-    omp_default = min(cb.lib.cb_max_threads(), cores)
-    ts, rs = zip(*[case.inputs(orc_mod, b) for b in range(8)])
-
-    def leg(nthreads, batch, budget):
-        t = np.tile(np.concatenate(ts), (batch + 7) // 8)[:batch * case.L * case.n].copy()
-        r = np.tile(np.concatenate(rs), (batch + 7) // 8)[:batch * 2 * case.L * case.n].copy()
-        cb.keyswitch_batch(r, t, nthreads)                       # warm-up (page faults, thread pool)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            cb.keyswitch_batch(r, t, nthreads)
-            done += batch
-            el = time.perf_counter() - t0
-            if el > budget:
-                return done / el, done, el
-
-    v1, n1, e1 = leg(1, 8, budget_s * 0.6)
-    legs = {}
-    for th in sorted({omp_default, cores}):
-        legs[th] = leg(th, 2 * th, budget_s * 0.7)
+    # (128 on the 2 x 64-core, 256-hardware-thread boxes of this pool)
+    physical = min(cb.lib.cb_max_threads(), cores)
+    ts, rs = zip(*[case.inputs(orc_mod, b) for b in range(2)])
+    ts, rs = np.concatenate(ts), np.concatenate(rs)
+    counts = sorted({c for c in (1, 16, 64, physical, cores) if c <= cores})
+    legs, nodes = {}, 0
+    for th in counts:
+        done, el, nodes, first = cb.keyswitch_timed(ts, rs, th, budget_s / len(counts) * (0.6 if th == 1 else 1.1))
+        assert np.array_equal(first, want), f"the timed CPU leg ({th} threads) disagrees with the oracle"
+        legs[th] = (done / el, done, el)
+    cb.close()
     threads = max(legs, key=lambda k: legs[k][0])
     va, na, ea = legs[threads]
-    cb.close()
+    v1 = legs[1][0]
     kind = "port" if isa == "scalar" else "port+" + isa
     return {"value": va, "unit": "keyswitches/s", "cores": threads, "kind": kind, "isa": isa, "value_1t": v1,
             "by_threads": {str(k): v[0] for k, v in legs.items()},
+            "parallel_efficiency": {str(k): v[0] / (k * v1) for k, v in legs.items()},
+            "numa_nodes_used": nodes,
             "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
-            "sample": f"{na} keyswitches N={case.n} L={case.L} K={case.K} in {ea:.1f}s on {threads} OpenMP threads "
-                      f"(one ciphertext per thread, affinity mask of {cores} of {os.cpu_count()} hardware threads; legs timed: "
-                      f"{', '.join(f'{k} threads {v[0]:.0f}/s' for k, v in legs.items())}); 1 thread: {n1} in {e1:.1f}s; "
-                      f"oracle/cpu_baseline.c: port of the reference's CPU algorithms (Harvey/Shoup NTT, Shoup key products) with "
-                      f"{isa} kernels chosen by HEXL's rule (IFMA below 2^50, 64-bit AVX512-DQ lanes above; these primes are "
-                      f"{int(case.moduli[0]).bit_length()}-bit), gcc -O3 -march=native -fopenmp; Intel HEXL itself is not in the image"}
+            "sample": f"{na} keyswitches N={case.n} L={case.L} K={case.K} in {ea:.1f}s on {threads} pinned OpenMP threads "
+                      f"(legs: {', '.join(f'{k} threads {v[0]:.0f}/s' for k, v in legs.items())}; each thread loops over its own two "
+                      f"ciphertexts, keys and tables replicated on {nodes} NUMA node(s)); oracle/cpu_baseline.c: port of the reference's "
+                      f"CPU algorithms (Harvey/Shoup NTT, Shoup key products) with {isa} kernels chosen by HEXL's rule (IFMA below 2^50, "
+                      f"64-bit AVX512-DQ lanes above; these primes are {int(case.moduli[0]).bit_length()}-bit), gcc -O3 -march=native "
+                      f"-fopenmp; Intel HEXL itself is not in the image"}
 
 
 def cxx_api_end_to_end(L, timeout_s=120):

@@ -57,6 +57,7 @@ extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->d_ntt_tab) (void)hipFree(c->d_ntt_tab);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_ntt_hint) (void)hipHostFree(c->h_ntt_hint);
     if (c->s_up) (void)hipStreamDestroy(c->s_up);
     if (c->s_down) (void)hipStreamDestroy(c->s_down);
     for (int i = 0; i < 2; ++i) {

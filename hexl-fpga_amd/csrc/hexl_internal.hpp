@@ -56,6 +56,10 @@ struct hexl_ctx {
     void* d_meta = nullptr;   size_t d_meta_bytes = 0;     // dyadic per-(item,modulus) constants
     void* d_ntt_tab = nullptr; size_t d_ntt_tab_bytes = 0;  // standalone NTT fast path: violation counters + derived double tables
     uint32_t ntt_seq = 0;                                   // launches so far (selects the violation counter)
+    // "these tables are not Shoup tables" hints from the fast-path kernels to the host (ntt.hip NttHint): four pinned words
+    unsigned long long *h_ntt_hint = nullptr, *d_ntt_hint = nullptr;
+    unsigned long long* ntt_hint_word = nullptr; unsigned long long ntt_hint_tag = 0;   // of the launch being set up
+    const uint32_t* ntt_clear_viol = nullptr;               // hinted route: the integer kernel clears the hint when this counter is 0
     char name[256] = {0};
 };
 

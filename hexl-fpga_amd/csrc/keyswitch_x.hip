@@ -432,7 +432,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 // multiple of q_i. SKIP: |y_k| <= 0.5 rho q_i goes into the transform as it is (standard schedule: 0.625 -> 3.77 after three
 // stages at rho = 1.25). The accumulators arrive un-reduced from mac_fold in the lazy kernels (|acc| <= 1.7p):
 // |acc - w| <= 1.7p + 2.14p = 3.84p < 2^53 = 3.97p, and mul_shoup of that is exact (|h| < 2^103, |h - k p| <= 1.5p).
-template <class G, class W, int FUSED_K = -1, bool SKIP = false>
+// PREF (KX_RMW_PREF builds, direct B-order read-modify-write only): the first PREF old result words are requested between the
+// transform's last re-deal and its partial pass (`before_last`), behind that pass's twiddles -- vector memory returns in order,
+// so nothing the pass waits for queues behind them -- instead of at the top of the epilogue, where all 16 waves of the workgroup
+// wait out an HBM latency together (~3 k cycles, twice per round). k = 0: 8 words (acc_1 is still live), k = 1: all 16.
+#ifndef KX_RMW_PREF
+#define KX_RMW_PREF 0
+#endif
+template <class G, class W, int FUSED_K = -1, bool SKIP = false, int PREF = 0>
 __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
                                                double* lds, int tid, const double* tb, const KsModF64& md, hxf::RangeMask& bad,
                                                const u64* a0 = nullptr, const u64* a1 = nullptr, const u64* b0 = nullptr,
@@ -442,9 +449,35 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
     }
-    W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);               // |w| <= 2.14p
+    constexpr int NPF = (FUSED_K < 0 && G::KL <= 2) ? PREF : 0;
+    u64 early[NPF > 0 ? NPF : 1];
+    if constexpr (NPF > 0) {
+        const u32 tBe = u32(G::idxB(0, tid));
+        auto request = [&] {
+#pragma unroll
+            for (int r = 0; r < NPF; ++r) early[r] = (res + G::idxB(r, 0))[tBe];
+        };
+        W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m, typename W::NoHook(), request);
+    } else {
+        W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);           // |w| <= 2.14p
+    }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
+    if constexpr (NPF > 0) {
+        const u32 tB = u32(G::idxB(0, tid));
+        const u64 qi = (u64)m.p;
+        u64 late[G::E - NPF > 0 ? G::E - NPF : 1];
+#pragma unroll
+        for (int r = NPF; r < G::E; ++r) late[r - NPF] = (res + G::idxB(r, 0))[tB];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            const u64 o = r < NPF ? early[r < NPF ? r : 0] : late[r >= NPF ? r - NPF : 0];
+            const double rr = hxf::reduce(hxf::to_f64_lt52_checked(o, qi, bad) + v[r], m);       // fpga.cpp:453-457
+            (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
+            if (r == NPF - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     if constexpr (FUSED_K >= 0 && G::KL <= 2) {
         const u32 tB = u32(G::idxB(0, tid));
         auto ld = [&](const u64* p, int r) { return hxf::reduce(hxf::to_f64((p + G::idxB(r, 0))[tB]), m); };
@@ -602,7 +635,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         KX_STAMP(4 * L + 0);
         const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W, -1, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
+        else ksx_down_round<G, W, -1, SKIP, (KX_RMW_PREF ? G::E / 2 : 0)>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
         const double* nxt = a.s + (size_t(bc) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -616,7 +649,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* tb = a.tables + toff;
         const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W, -1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
+        else ksx_down_round<G, W, -1, SKIP, (KX_RMW_PREF ? G::E : 0)>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
         KX_STAMP(4 * L + 8);
         hxf::report_range(bad, a.range_flag);
     }

@@ -3,6 +3,7 @@
 // ntt_output_kernel :582-604) and device/inv_ntt.cpp (:83-571) of the reference.
 // One workgroup per polynomial; see ntt_core.hpp for the register/LDS mapping.
 #include <stdlib.h>
+#include <string.h>
 
 #include "hexl_internal.hpp"
 #include "ntt_core.hpp"
@@ -68,12 +69,20 @@ __device__ __attribute__((noinline)) void slow_inv(u64* px, u64* lds, const u64*
     for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
 }
 
+// Tables that are NOT Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random words): the fast-path kernels find out from
+// the prepare kernel's counter at kernel entry and run the integer butterflies (slow_fwd / slow_inv) on the whole batch -- correct,
+// but through an out-of-line call whose twiddle loads are not scalar (measured 0.154 ms per 1024 polynomials against 0.119 ms for the
+// dedicated integer kernels). So they also leave a HINT for the host: a tag of (table pointers, q, n) in a pinned host word. The
+// next call with the same tag goes to the dedicated integer kernels straight away -- which are correct for ANY tables, so a stale
+// or colliding hint can only cost speed -- still runs the prepare kernel, and clears the hint once the tables verify.
+struct NttHint { unsigned long long* word; unsigned long long tag; };
+
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restrict__ x, const u64* __restrict__ roots,
                                                                   const u64* __restrict__ precon, u64 q,
                                                                   const double* __restrict__ w,
                                                                   const double* __restrict__ wp,
-                                                                  const u32* __restrict__ violations, u32 batch) {
+                                                                  const u32* __restrict__ violations, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
@@ -82,7 +91,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     u64* px = x + size_t(p) * G::N;
     // tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones) are known at kernel
     // entry and wave-uniform: straight to the integer butterflies, no FP64 transform first (round 4)
-    if (*violations != 0) { slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q); return; }
+    if (*violations != 0) {
+        if (p == 0 && tid == 0) *hint.word = hint.tag;
+        slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
+        return;
+    }
     const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
     const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
@@ -112,14 +125,18 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
                                                                   u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p,
                                                                   const double* __restrict__ w,
                                                                   const double* __restrict__ wp, hxf::InvScale sc,
-                                                                  const u32* __restrict__ violations, u32 batch) {
+                                                                  const u32* __restrict__ violations, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
     const u32 p = blockIdx.x;
     if (p >= batch) return;
     u64* px = x + size_t(p) * G::N;
-    if (*violations != 0) { slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p); return; }   // see k_ntt_fwd_x
+    if (*violations != 0) {                                                     // see k_ntt_fwd_x
+        if (p == 0 && tid == 0) *hint.word = hint.tag;
+        slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        return;
+    }
     const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
     const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
                                                                   const u64* __restrict__ precon, u64 q,
                                                                   const double* __restrict__ w,
                                                                   const double* __restrict__ wp,
-                                                                  const u32* __restrict__ violations, u32 batch) {
+                                                                  const u32* __restrict__ violations, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         // Tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones): known at kernel entry,
         // the same for every polynomial and wave-uniform -- the whole batch goes straight through the integer butterflies.
         // (Rounds 2-3 ran the FP64 transform on every polynomial first and only then fell back: the transform twice.)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
 #pragma unroll 1
         for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
             slow_fwd<LOGN, LOGE>(x + size_t(p) * G::N, lds, roots, precon, q);
@@ -239,12 +257,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
                                                                   u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p,
                                                                   const double* __restrict__ w,
                                                                   const double* __restrict__ wp, hxf::InvScale sc,
-                                                                  const u32* __restrict__ violations, u32 batch) {
+                                                                  const u32* __restrict__ violations, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
     const Mod m{(double)q, 1.0 / (double)q};
     if (*violations != 0) {                                                     // see k_ntt_fwd_p
+        if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
 #pragma unroll 1
         for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
             slow_inv<LOGN, LOGE>(x + size_t(p) * G::N, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
@@ -312,6 +331,11 @@ static int prepare_tables(hexl_ctx* ctx, const u64* roots, const u64* precon, u6
     u32* counters = (u32*)ctx->d_ntt_tab;
     *w = (double*)((char*)ctx->d_ntt_tab + 256);
     *wp = *w + n;
+    if (!ctx->h_ntt_hint) {                                        // NttHint: four pinned, device-visible words
+        HX_CHECK(hipHostMalloc((void**)&ctx->h_ntt_hint, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(ctx->h_ntt_hint, 0, 4 * sizeof(unsigned long long));
+        HX_CHECK(hipHostGetDevicePointer((void**)&ctx->d_ntt_hint, ctx->h_ntt_hint, 0));
+    }
     const u32 seq = ctx->ntt_seq++;
     *viol = counters + (seq & 63);
     hipLaunchKernelGGL(k_ntt_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, roots, precon, q,
@@ -323,10 +347,13 @@ template <int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd(u64* __restrict__ x,
                                                                 const u64* __restrict__ roots,
                                                                 const u64* __restrict__ precon, u64 q,
-                                                                u32 batch) {
+                                                                u32 batch, const u32* __restrict__ viol = nullptr,
+                                                                unsigned long long* hint_word = nullptr) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
+    // hinted route (NttHint above): the tables verified this time -> the next call takes the fast path again
+    if (hint_word && blockIdx.x == 0 && tid == 0 && *viol == 0) *hint_word = 0;
     {
         const u32 p = blockIdx.x;   // one workgroup per polynomial (grid == batch)
         if (p >= batch) return;
@@ -346,10 +373,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv(u64* __restrict_
                                                                 const u64* __restrict__ iroots,
                                                                 const u64* __restrict__ iprecon, u64 q,
                                                                 u64 inv_n, u64 inv_n_p, u64 inv_n_w,
-                                                                u64 inv_n_w_p, u32 batch) {
+                                                                u64 inv_n_w_p, u32 batch, const u32* __restrict__ viol = nullptr,
+                                                                unsigned long long* hint_word = nullptr) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
+    if (hint_word && blockIdx.x == 0 && tid == 0 && *viol == 0) *hint_word = 0;      // see k_ntt_fwd
     {
         const u32 p = blockIdx.x;   // one workgroup per polynomial (grid == batch)
         if (p >= batch) return;
@@ -370,9 +399,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv(u64* __restrict_
 template <int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_ip(u64* __restrict__ x, const u64* __restrict__ iroots,
                                                                    const u64* __restrict__ iprecon, u64 q, u64 inv_n,
-                                                                   u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, u32 batch) {
+                                                                   u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, u32 batch,
+                                                                   const u32* __restrict__ viol = nullptr,
+                                                                   unsigned long long* hint_word = nullptr) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    if (hint_word && blockIdx.x == 0 && threadIdx.x == 0 && *viol == 0) *hint_word = 0;      // see k_ntt_fwd
     u64 raw[G::E];
     {
         const int tid = threadIdx.x;
@@ -426,7 +458,7 @@ static int launch_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
         }))
         return rc;
     hipLaunchKernelGGL((k_ntt_fwd<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
-                       roots, precon, q, (u32)batch);
+                       roots, precon, q, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
     return (int)hipGetLastError();
 }
 
@@ -450,11 +482,11 @@ static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
             }))
             return rc;
         hipLaunchKernelGGL((k_ntt_inv_ip<LOGN, LOGE>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x, ir, ip,
-                           q, a, ap, b, bp, (u32)batch);
+                           q, a, ap, b, bp, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_ntt_inv<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x, ir,
-                       ip, q, a, ap, b, bp, (u32)batch);
+                       ip, q, a, ap, b, bp, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
     return (int)hipGetLastError();
 }
 
@@ -480,11 +512,11 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
             }))
             return rc;
         hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
-                           roots, precon, q, w, wp, viol, (u32)batch);
+                           roots, precon, q, w, wp, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
-                       roots, precon, q, w, wp, viol, (u32)batch);
+                       roots, precon, q, w, wp, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
     return (int)hipGetLastError();
 }
 
@@ -508,11 +540,11 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
             }))
             return rc;
         hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
-                           ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
+                           ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
-                       ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch);
+                       ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
     return (int)hipGetLastError();
 }
 
@@ -565,18 +597,36 @@ static int ilog2_exact(u64 n) {
     return -1;
 }
 
+// tag of a table set (never 0) and its hint slot; true when a previous launch on this context flagged exactly this set
+static bool ntt_hinted(hexl_ctx* ctx, const u64* t0, const u64* t1, u64 q, u64 n, int dir) {
+    u64 z = (u64)(uintptr_t)t0 * 0x9E3779B97F4A7C15ull ^ (u64)(uintptr_t)t1 * 0xBF58476D1CE4E5B9ull ^ q * 0x94D049BB133111EBull ^ (n << 1) ^ (u64)dir;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    ctx->ntt_hint_tag = z | 1;
+    const u32 slot = (u32)(z >> 60) & 3;
+    ctx->ntt_hint_word = ctx->d_ntt_hint + slot;
+    return ((volatile unsigned long long*)ctx->h_ntt_hint)[slot] == ctx->ntt_hint_tag;
+}
+
 int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q, u64 n) {
     if (!batch) return 0;
     const int logn = ilog2_exact(n);
+    ctx->ntt_clear_viol = nullptr;
     if (fast_path_enabled() && q >= (1ull << 16) && q < (1ull << 52)) {
         double *w, *wp; u32* viol;
         int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol);
         if (rc) return rc;
+        // a previous call found these tables not to be Shoup tables: the dedicated integer kernels, which also clear the hint
+        // once the prepare kernel (still run, above) finds the tables genuine
+        const bool hinted = ntt_hinted(ctx, roots, precon, q, n, 0);
+        if (hinted) ctx->ntt_clear_viol = viol;
         const int period = hxf::lazy_period_for((double)q);       // fewer range reductions for smaller moduli (N = 16384)
-        if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, w, wp, viol);
-        if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, w, wp, viol);
-        return period ? dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
-                      : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+        if (!hinted) {
+            if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, w, wp, viol);
+            if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, w, wp, viol);
+            return period ? dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
+                          : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+        }
     }
     switch (logn) {
         case 10: return launch_fwd<10, 4>(ctx, x, batch, roots, precon, q);
@@ -595,16 +645,20 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
                       u64 b, u64 bp, u64 n) {
     if (!batch) return 0;
     const int logn = ilog2_exact(n);
+    ctx->ntt_clear_viol = nullptr;
     if (fast_path_enabled() && q >= (1ull << 16) && q < (1ull << 52) && a < q && b < q) {
         double *w, *wp; u32* viol;
         int rc = prepare_tables(ctx, ir, ip, q, n, &w, &wp, &viol);
         if (rc) return rc;
+        const bool hinted = ntt_hinted(ctx, ir, ip, q, n, 1);     // see hx_launch_ntt_fwd
+        if (hinted) ctx->ntt_clear_viol = viol;
         const double pd = (double)q;
         auto centre = [&](u64 v) { return v > q / 2 ? (double)v - pd : (double)v; };
         hxf::InvScale sc;
         sc.n = centre(a); sc.n_p = sc.n / pd; sc.nw = centre(b); sc.nw_p = sc.nw / pd;
-        return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<3>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol)
-                                           : dispatch_inv_x<0>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol);
+        if (!hinted)
+            return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<3>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol)
+                                               : dispatch_inv_x<0>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol);
     }
     switch (logn) {
         case 10: return launch_inv<10, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp);

@@ -17,9 +17,15 @@
  * scalar port. Every path is lazy inside and fully reduced at the end, so all of them return the oracle's words.
  * kind = "port+avx512ifma" / "port+avx512dq" / "port" in the bench line.
  */
+#define _GNU_SOURCE
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -38,11 +44,24 @@ typedef struct {
                                    /* floor(. * 2^52 / q) instead of floor(. * 2^64 / q) */
 } cb_mod;
 
+/* everything a keyswitch READS besides its own ciphertext: per-modulus constants + tables, keys, key Shoup factors. The plan
+ * holds one view over the caller's / its own arrays; cb_keyswitch_timed adds one replica per NUMA node its threads run on
+ * (round 4: with a single copy first-touched by one thread, 128 threads pulled 29 MB per keyswitch out of one node's memory:
+ * 3.9 % parallel efficiency). */
+struct cb_view {
+    cb_mod* m;                     /* [K] */
+    const uint64_t* const* keys;   /* keys[d][(k*K+i)*n+j] */
+    uint64_t** key_p;              /* Shoup factors of the keys: [d][(k*(L+1)+slot)*n+j] */
+};
+#define CB_MAX_NODES 16
 struct cb_plan {
     uint64_t n, L, K;
     cb_mod* m;                     /* [K] */
     const uint64_t* const* keys;   /* caller-owned: keys[d][(k*K+i)*n+j] */
     uint64_t** key_p;              /* Shoup factors of the keys: [d][(k*(L+1)+slot)*n+j] */
+    int nrep;                      /* NUMA replicas made so far */
+    int rep_node[CB_MAX_NODES];
+    struct cb_view rep[CB_MAX_NODES];
 };
 
 static inline uint64_t mulhi(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) >> 64); }
@@ -267,8 +286,15 @@ struct cb_plan* cb_plan_create(uint64_t n, uint64_t L, uint64_t K, const uint64_
     return p;
 }
 
+static void free_view(const struct cb_plan* p, struct cb_view* v) {
+    for (uint64_t i = 0; i < p->K; i++) { free(v->m[i].w); free(v->m[i].wp); free(v->m[i].iw); free(v->m[i].iwp); }
+    for (uint64_t d = 0; d < p->L; d++) { free((void*)v->keys[d]); free(v->key_p[d]); }
+    free(v->m); free((void*)v->keys); free(v->key_p);
+}
+
 void cb_plan_destroy(struct cb_plan* p) {
     if (!p) return;
+    for (int r = 0; r < p->nrep; r++) free_view(p, &p->rep[r]);
     for (uint64_t i = 0; i < p->K; i++) { free(p->m[i].w); free(p->m[i].wp); free(p->m[i].iw); free(p->m[i].iwp); }
     for (uint64_t d = 0; d < p->L; d++) free(p->key_p[d]);
     free(p->key_p); free(p->m); free(p);
@@ -343,8 +369,8 @@ static void mod_down(uint64_t* res, const uint64_t* pr, const uint64_t* u, uint6
 const char* cb_isa(const struct cb_plan* p) { return p->m[0].isa == 2 ? "avx512ifma" : p->m[0].isa == 1 ? "avx512dq" : "scalar"; }
 
 /* one keyswitch, SURVEY 2.1-K4 steps 1-7, result accumulated into; `ws` = (L + 2(L+1) + 2) * n words of scratch */
-static void cb_one(const struct cb_plan* p, uint64_t* result, const uint64_t* t_target, uint64_t* ws) {
-    const uint64_t n = p->n, L = p->L, K = p->K, sp = K - 1;
+static void cb_one_v(const struct cb_plan* pl, const struct cb_view* p, uint64_t* result, const uint64_t* t_target, uint64_t* ws) {
+    const uint64_t n = pl->n, L = pl->L, K = pl->K, sp = K - 1;
     uint64_t *c = ws, *prod = c + L * n, *u = prod + 2 * (L + 1) * n, *s = u + n;
     memset(prod, 0, 2 * (L + 1) * n * 8);
     for (uint64_t d = 0; d < L; d++) {
@@ -379,6 +405,133 @@ static void cb_one(const struct cb_plan* p, uint64_t* result, const uint64_t* t_
             mod_down(result + (k * L + i) * n, pr, u, n, m);
         }
     }
+}
+
+static void cb_one(const struct cb_plan* p, uint64_t* result, const uint64_t* t_target, uint64_t* ws) {
+    const struct cb_view v = {p->m, p->keys, p->key_p};
+    cb_one_v(p, &v, result, t_target, ws);
+}
+
+/* ---- the timed leg: pinned threads, NUMA-local data ------------------------------------------------------------------------ */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+/* the CPUs this process may use, physical cores first (a CPU that is the first of its SMT sibling list), then the siblings */
+static int cpu_order(int* out, int max, int* n_physical) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set)) return 0;
+    int n = 0, nphys = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int c = 0; c < CPU_SETSIZE && n < max; c++) {
+            if (!CPU_ISSET(c, &set)) continue;
+            char path[128]; int first = c;
+            snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            FILE* f = fopen(path, "r");
+            if (f) { if (fscanf(f, "%d", &first) != 1) first = c; fclose(f); }
+            const int is_first = (first == c) || !CPU_ISSET(first, &set);
+            if ((pass == 0) == is_first) { out[n++] = c; if (pass == 0) nphys++; }
+        }
+    *n_physical = nphys;
+    return n;
+}
+
+/* a replica of everything read-only, allocated and first-touched by the calling thread (i.e. on its NUMA node) */
+static void make_view(const struct cb_plan* p, struct cb_view* v) {
+    const uint64_t n = p->n, L = p->L, K = p->K;
+    v->m = (cb_mod*)malloc(K * sizeof(cb_mod));
+    memcpy(v->m, p->m, K * sizeof(cb_mod));
+    for (uint64_t i = 0; i < K; i++) {
+        uint64_t** dst[4] = {&v->m[i].w, &v->m[i].wp, &v->m[i].iw, &v->m[i].iwp};
+        uint64_t* src[4] = {p->m[i].w, p->m[i].wp, p->m[i].iw, p->m[i].iwp};
+        for (int t = 0; t < 4; t++) { *dst[t] = (uint64_t*)malloc(n * 8); memcpy(*dst[t], src[t], n * 8); }
+    }
+    uint64_t** keys = (uint64_t**)malloc(L * sizeof(uint64_t*));
+    v->key_p = (uint64_t**)malloc(L * sizeof(uint64_t*));
+    for (uint64_t d = 0; d < L; d++) {
+        keys[d] = (uint64_t*)malloc(2 * K * n * 8);        memcpy(keys[d], p->keys[d], 2 * K * n * 8);
+        v->key_p[d] = (uint64_t*)malloc(2 * (L + 1) * n * 8); memcpy(v->key_p[d], p->key_p[d], 2 * (L + 1) * n * 8);
+    }
+    v->keys = (const uint64_t* const*)keys;
+}
+
+/* `threads` OpenMP threads, each PINNED to its own CPU of the process's affinity mask (physical cores first, spread evenly over
+ * them when there are fewer threads than cores), each with a private, first-touched copy of the `nsrc` source instances and its
+ * own scratch; keys, key Shoup factors and twiddle tables replicated once per NUMA node the threads land on. Every thread walks
+ * its instances (result accumulated in place, like the library) until `seconds` have passed. Returns the number of keyswitches
+ * done by all threads; *elapsed = the slowest thread's time; *nodes = NUMA nodes used; `first_out` (2 L n words, may be NULL)
+ * receives thread 0's first result after ONE keyswitch so that the caller can check this path against the oracle. */
+uint64_t cb_keyswitch_timed(struct cb_plan* p, const uint64_t* t_src, const uint64_t* r_src, uint64_t nsrc, int threads,
+                            double seconds, double* elapsed, int* nodes, uint64_t* first_out) {
+    const uint64_t n = p->n, L = p->L;
+    const size_t ws_words = (L + 2 * (L + 1) + 2) * n;
+    static int cpus[4096];
+    int nphys = 0;
+    const int ncpu = cpu_order(cpus, 4096, &nphys);
+    uint64_t total = 0;
+    double worst = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+#pragma omp parallel num_threads(threads) reduction(+ : total) reduction(max : worst)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int t = 0, nt = 1;
+#endif
+        if (ncpu > 0) {
+            /* fewer threads than physical cores: every (nphys / nt)-th core, which spreads them over the sockets and L3 slices */
+            const int idx = nt <= nphys ? (int)((long)t * nphys / nt) : t % ncpu;
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[idx], &one);
+            sched_setaffinity(0, sizeof(one), &one);
+        }
+        unsigned cpu = 0, node = 0;
+        syscall(SYS_getcpu, &cpu, &node, NULL);
+        const struct cb_view* view = NULL;
+#pragma omp critical(cb_replicate)
+        {
+            for (int r = 0; r < p->nrep; r++) if (p->rep_node[r] == (int)node) view = &p->rep[r];
+            if (!view && p->nrep < CB_MAX_NODES) {                 /* first thread of this node: allocate + first-touch here */
+                make_view(p, &p->rep[p->nrep]);
+                p->rep_node[p->nrep] = (int)node;
+                view = &p->rep[p->nrep++];
+            }
+        }
+        const struct cb_view fallback = {p->m, p->keys, p->key_p};
+        if (!view) view = &fallback;
+        uint64_t* ws = (uint64_t*)malloc(ws_words * 8);
+        uint64_t* tt = (uint64_t*)malloc(nsrc * L * n * 8);
+        uint64_t* rr = (uint64_t*)malloc(nsrc * 2 * L * n * 8);
+        memcpy(tt, t_src, nsrc * L * n * 8);
+        memcpy(rr, r_src, nsrc * 2 * L * n * 8);
+        memset(ws, 0, ws_words * 8);
+        cb_one_v(p, view, rr, tt, ws);                              /* warm-up = the checked keyswitch */
+        if (t == 0 && first_out) memcpy(first_out, rr, 2 * L * n * 8);
+#pragma omp barrier
+        const double t0 = now_s();
+        uint64_t done = 0;
+        for (uint64_t b = 0;; b = (b + 1) % nsrc) {
+            cb_one_v(p, view, rr + b * 2 * L * n, tt + b * L * n, ws);
+            ++done;
+            if (now_s() - t0 >= seconds) break;
+        }
+        worst = now_s() - t0;
+        total = done;
+        free(ws); free(tt); free(rr);
+        if (ncpu > 0) {                                             /* give the thread back its full mask (the pool is reused) */
+            cpu_set_t all;
+            CPU_ZERO(&all);
+            for (int i = 0; i < ncpu; i++) CPU_SET(cpus[i], &all);
+            sched_setaffinity(0, sizeof(all), &all);
+        }
+    }
+    if (elapsed) *elapsed = worst;
+    if (nodes) *nodes = p->nrep;
+    return total;
 }
 
 /* batch of independent keyswitches, `threads` OpenMP threads (0 = all); returns the number of threads used */

@@ -165,6 +165,9 @@ def cpu_baseline_lib(march: str = "native") -> ctypes.CDLL:
         L.cb_plan_destroy.restype = None; L.cb_plan_destroy.argtypes = [ctypes.c_void_p]
         L.cb_keyswitch_batch.restype = ctypes.c_int
         L.cb_keyswitch_batch.argtypes = [ctypes.c_void_p, P, P, u64, ctypes.c_int]
+        L.cb_keyswitch_timed.restype = u64
+        L.cb_keyswitch_timed.argtypes = [ctypes.c_void_p, P, P, u64, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_int), P]
         L.cb_ntt_fwd_batch.restype = ctypes.c_int
         L.cb_ntt_fwd_batch.argtypes = [ctypes.c_void_p, u64, P, u64, ctypes.c_int]
         L.cb_max_threads.restype = ctypes.c_int; L.cb_max_threads.argtypes = []
@@ -189,6 +192,16 @@ class CpuKeySwitch:
         batch = ts.size // (self.L * self.n)
         assert results.size == batch * 2 * self.L * self.n
         return self.lib.cb_keyswitch_batch(self.h, p(results), p(ts), batch, threads)
+
+    def keyswitch_timed(self, ts: np.ndarray, rs: np.ndarray, threads: int, seconds: float):
+        """the benchmark leg: pinned threads, private first-touched ciphertexts, keys / tables replicated per NUMA node; returns
+        (keyswitches done, seconds of the slowest thread, NUMA nodes used, thread 0's first result after one keyswitch)"""
+        nsrc = ts.size // (self.L * self.n)
+        assert rs.size == nsrc * 2 * self.L * self.n
+        el, nodes = ctypes.c_double(0), ctypes.c_int(0)
+        first = np.empty(2 * self.L * self.n, dtype=np.uint64)
+        done = self.lib.cb_keyswitch_timed(self.h, p(ts), p(rs), nsrc, threads, seconds, ctypes.byref(el), ctypes.byref(nodes), p(first))
+        return int(done), el.value, nodes.value, first
 
     def isa(self) -> str:
         """kernels the plan's first modulus runs on: scalar / avx512dq / avx512ifma (HEXL's rule; HEXL_CPU_ISA restricts)"""

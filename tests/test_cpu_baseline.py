@@ -75,3 +75,22 @@ def test_vector_kernels_on_a_mixed_prime_chain(orc):
     cb.keyswitch_batch(got, t, 1)
     cb.close()
     assert np.array_equal(got, case.expected(orc, t, r))
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_timed_numa_leg_equals_oracle(orc, threads):
+    """cb_keyswitch_timed (bench.py's CPU leg since round 4: pinned threads, private ciphertexts, NUMA replicas of keys and tables)
+    runs the same keyswitch: thread 0's first result equals the oracle's, the counters make sense, the plan survives a second leg"""
+    n, L, K = 4096, 3, 4
+    case = KsCase(orc, n, L, K, seed=21)
+    cb = orc.CpuKeySwitch(n, L, K, case.moduli, case.keys, case.modswitch, march="native")
+    ts, rs = zip(*[case.inputs(orc, b) for b in range(2)])
+    for _ in range(2):
+        done, el, nodes, first = cb.keyswitch_timed(np.concatenate(ts), np.concatenate(rs), threads, 0.15)
+        assert done >= threads and 0.1 < el < 5.0 and nodes >= 1
+        assert np.array_equal(first, case.expected(orc, ts[0], rs[0]))
+    # the plain batch entry point still works on the same plan afterwards
+    got = rs[1].copy()
+    cb.keyswitch_batch(got, ts[1], 1)
+    assert np.array_equal(got, case.expected(orc, ts[1], rs[1]))
+    cb.close()

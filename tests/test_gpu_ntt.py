@@ -112,17 +112,20 @@ for arr in (t.roots, t.precon, t.inv_roots, t.inv_precon):
     arr[:] = rng.integers(0, q, size=n, dtype=np.uint64)
 t.inv_n, t.inv_n_w = int(rng.integers(0, q)), int(rng.integers(0, q))
 x = rng.integers(0, q, size=(8, n), dtype=np.uint64)
-d = hx.as_i64(np.tile(x, (batch // 8, 1)).reshape(-1)).to(dev)
+d_in = hx.as_i64(np.tile(x, (batch // 8, 1)).reshape(-1)).to(dev)
+d = d_in.clone()
 tabs = [hx.as_i64(a).to(dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
 res = {}
 for name in ("fwd", "inv"):
     run = (lambda: ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)) if name == "fwd" else (lambda: ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n))
-    d0 = d.clone()
-    run(); ctx.sync()
+    d.copy_(d_in)
+    run(); ctx.sync()                                         # (the first call also leaves the host its hint: ntt.hip NttHint)
     got = hx.to_u64(d).reshape(batch, n)
     want = orc.ntt_fwd(x, t) if name == "fwd" else orc.ntt_inv(x, t)
     res[name + "_exact"] = bool(np.array_equal(got[:8], want) and np.array_equal(got[-8:], want))
-    d.copy_(d0)
+    d.copy_(d_in)
+    run(); ctx.sync()                                         # second call: the hinted route, same bits
+    res[name + "_exact"] = res[name + "_exact"] and bool(np.array_equal(hx.to_u64(d).reshape(batch, n)[-8:], want))
     for _ in range(20): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--masks", default="0,1,2,4,8,16,31")
     ap.add_argument("--rate-guess", type=float, default=200e3, help="keyswitch/s used to size the power legs")
     a = ap.parse_args()
-    out = Path(a.out)
+    out = Path(a.out).resolve()                                    # rocprofv3 runs with cwd = /tmp
     out.mkdir(parents=True, exist_ok=True)
     exe = ROOT / "tools" / "pmc_workload_prof"
     assert exe.exists(), "tools/pmc_workload_prof not built (make -C tools)"
@@ -151,9 +151,10 @@ def main():
                     tot[kk] = tot.get(kk, 0.0) + vv
         e["pipeline"] = tot
         # 2. the power leg
-        reps = max(4, int(a.power_seconds * a.rate_guess / 2048))
+        reps = max(4, int(a.power_seconds * a.rate_guess / 4096))
         try:
-            r = subprocess.run([str(exe), "2048", str(L), str(reps)], env=dict(env, HEXL_WORKLOAD_POWER="1"), capture_output=True, text=True, timeout=300)
+            penv = {k: v for k, v in env.items() if k != "HEXL_KS_ONE_LANE"}     # the shipped two-lane schedule, as bench.py times it
+            r = subprocess.run([str(exe), "4096", str(L), str(reps)], env=dict(penv, HEXL_WORKLOAD_POWER="1"), capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             e["power_leg"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-200:]}
         except Exception as ex:

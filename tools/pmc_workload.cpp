@@ -40,18 +40,25 @@ struct PowerProbe {
         return v;
     }
     PowerProbe() {
-        glob_t g{};
-        if (!::glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", 0, nullptr, &g) && g.gl_pathc) {
-            dir = g.gl_pathv[0];
-            dir = dir.substr(0, dir.rfind('/'));
+        // an amdgpu hwmon directory: it reports board power (power1_average or power1_input) AND the shader clock (freq1_input)
+        for (const char* pat : {"/sys/class/drm/card*/device/hwmon/hwmon*", "/sys/bus/pci/devices/*/hwmon/hwmon*", "/sys/class/hwmon/hwmon*"}) {
+            glob_t g{};
+            if (!::glob(pat, 0, nullptr, &g))
+                for (size_t i = 0; i < g.gl_pathc && dir.empty(); ++i) {
+                    const std::string d = g.gl_pathv[i];
+                    if (read(d + "/freq1_input") > 0 && (read(d + "/power1_average") > 0 || read(d + "/power1_input") > 0)) dir = d;
+                }
+            globfree(&g);
+            if (!dir.empty()) break;
         }
-        globfree(&g);
     }
     void start() {
         if (dir.empty()) return;
         th = std::thread([this] {
             while (!stop.load()) {
-                const double w = read(dir + "/power1_average"), f = read(dir + "/freq1_input");
+                double w = read(dir + "/power1_average");
+                if (w <= 0) w = read(dir + "/power1_input");
+                const double f = read(dir + "/freq1_input");
                 if (w > 0) { w_sum += w / 1e6; w_max = w / 1e6 > w_max ? w / 1e6 : w_max; ++n; }
                 if (f > 0) { f_sum += f / 1e6; ++nf; }
                 std::this_thread::sleep_for(std::chrono::milliseconds(50));
