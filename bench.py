@@ -136,6 +136,25 @@ def time_dyadic(hx, ctx, orc_mod, dev, batch=4096, n=8192, nm=4, iters=5):
     return {"ms_per_launch": ms, "items_per_s": batch / (ms * 1e-3), "alg_GBps": batch * 7 * nm * n * 8 / (ms * 1e-3) / 1e9}
 
 
+def cpu_quota_cores():
+    """the container's CFS CPU quota in cores (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None: threads beyond it are throttled,
+    which is what the timed legs and the STREAM probe of `cpu_baseline` show on the pods of this pool"""
+    try:
+        parts = open("/sys/fs/cgroup/cpu.max").read().split()
+        if parts and parts[0] != "max":
+            return float(parts[0]) / float(parts[1])
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / p
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(orc_mod, case, budget_s=24.0):
     """oracle/cpu_baseline.c (Harvey/Shoup port of the reference's CPU algorithms with the AVX-512 kernels HEXL's rule selects, built
     -O3 -march=native on THIS host) timed on the host cores with its NUMA-aware leg (cb_keyswitch_timed, round 4): every OpenMP
@@ -163,6 +182,10 @@ def cpu_baseline(orc_mod, case, budget_s=24.0):
         done, el, nodes, first = cb.keyswitch_timed(ts, rs, th, budget_s / len(counts) * (0.6 if th == 1 else 1.1))
         assert np.array_equal(first, want), f"the timed CPU leg ({th} threads) disagrees with the oracle"
         legs[th] = (done / el, done, el)
+    # what the host's memory system gives this process at the same thread placements (STREAM-style triad, 64 MiB per array and
+    # thread): the keyswitch port streams 29 MB of keys + key factors per keyswitch and thread, so beyond one thread per L3 slice
+    # its scaling is bounded by this number, not by the cores
+    stream = {str(th): max(cb.lib.cb_stream_triad(th, 0.4, 64) for _ in range(2)) for th in counts if th > 1}   # best of two
     cb.close()
     threads = max(legs, key=lambda k: legs[k][0])
     va, na, ea = legs[threads]
@@ -171,7 +194,8 @@ def cpu_baseline(orc_mod, case, budget_s=24.0):
     return {"value": va, "unit": "keyswitches/s", "cores": threads, "kind": kind, "isa": isa, "value_1t": v1,
             "by_threads": {str(k): v[0] for k, v in legs.items()},
             "parallel_efficiency": {str(k): v[0] / (k * v1) for k, v in legs.items()},
-            "numa_nodes_used": nodes,
+            "numa_nodes_used": nodes, "host_stream_triad_GBps_by_threads": stream, "cgroup_cpu_quota_cores": cpu_quota_cores(),
+            "bytes_streamed_per_keyswitch_and_thread": int(2 * case.L * (case.L + 1) * 2 * case.n * 8 + 5 * case.L * case.n * 8),
             "host_cores_visible": cores, "host_cores_total": os.cpu_count(),
             "sample": f"{na} keyswitches N={case.n} L={case.L} K={case.K} in {ea:.1f}s on {threads} pinned OpenMP threads "
                       f"(legs: {', '.join(f'{k} threads {v[0]:.0f}/s' for k, v in legs.items())}; each thread loops over its own two "

@@ -247,6 +247,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         HX_CHECK(hipMalloc((void**)&p->d_tables_f64, ft.size() * sizeof(double)));
         HX_CHECK(hipMalloc((void**)&p->d_keys_f64, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
         if (logn >= 10 && logn <= 14) HX_CHECK(hipMalloc((void**)&p->d_keys_x, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
+        if (logn == 14) HX_CHECK(hipMalloc((void**)&p->d_keys_nat, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
         HX_CHECK(hipMemcpy(p->d_mods_f64, fm.data(), K * sizeof(KsModF64), hipMemcpyHostToDevice));
         HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -281,6 +282,7 @@ extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
     if (p->d_tables_f64) (void)hipFree(p->d_tables_f64);
     if (p->d_keys_f64) (void)hipFree(p->d_keys_f64);
     if (p->d_keys_x) (void)hipFree(p->d_keys_x);
+    if (p->d_keys_nat) (void)hipFree(p->d_keys_nat);
     if (p->d_flag) (void)hipFree(p->d_flag);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
     delete p;
@@ -300,7 +302,8 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     std::vector<u32> perm;
     const size_t words = size_t(L) * (L + 1) * 2 * n;
     if (!p->use_f64) { dev.resize(2 * words); perm = ks_perm(p->logn, p->int_loge); }
-    std::vector<double> devf, devx;
+    std::vector<double> devf, devx, devn;
+    if (p->d_keys_nat) devn.resize(words);
     std::vector<u32> permf, permx;
     if (p->use_f64) { devf.resize(words); permf = ks_perm(p->logn, p->f64_loge); }
     if (p->d_keys_x) { devx.resize(words); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
@@ -328,6 +331,11 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
                         const u64 v = src[permx[j]] % q;
                         devx[base + j] = v > q / 2 ? (double)v - (double)q : (double)v;
                     }
+                if (p->d_keys_nat)                                       // natural order (latency path)
+                    for (u64 j = 0; j < n; ++j) {
+                        const u64 v = src[j] % q;
+                        devn[base + j] = v > q / 2 ? (double)v - (double)q : (double)v;
+                    }
             }
         }
     }
@@ -337,6 +345,8 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
         HX_CHECK(hipMemcpy(p->d_keys_f64, devf.data(), devf.size() * sizeof(double), hipMemcpyHostToDevice));
     if (p->d_keys_x)
         HX_CHECK(hipMemcpy(p->d_keys_x, devx.data(), devx.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (p->d_keys_nat)
+        HX_CHECK(hipMemcpy(p->d_keys_nat, devn.data(), devn.size() * sizeof(double), hipMemcpyHostToDevice));
     p->have_keys = true;
     return 0;
 }

@@ -115,6 +115,7 @@ struct hexl_ks_plan {
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     u32* d_flag = nullptr;            // one device word + its pinned host mirror: input-range flag (HEXL_KS_VALIDATE)
     u32* h_flag = nullptr;
+    double* d_keys_nat = nullptr;     // N = 16384 FP64 plans: the keys as centred doubles in NATURAL order (latency path, keyswitch_lat.hip)
     bool x_skip = false;              // slot-major lazy kernels: moduli within LAZY_SKIP_MAX_RATIO of each other -> c_d and s' enter the
                                       // transforms without a range reduction (keyswitch_x.hip SKIP variants; HEXL_KSX_SKIP=0 turns it off)
     bool overwrite_result = false;    // host-pointer path, (b, d)-major FP64 kernels: write `result` instead of accumulating into it
@@ -139,6 +140,9 @@ int hx_launch_keyswitch_x(hexl_ks_plan*, u64* d_result, const u64* d_t_target, s
 bool hx_ks_x_applies(const hexl_ks_plan*, size_t nb);
 // true when a batch of nb runs entirely on kernels that honour hexl_ks_plan::overwrite_result
 bool hx_ks_can_overwrite(const hexl_ks_plan*, size_t nb);
+// the lone-keyswitch latency path (keyswitch_lat.hip): N = 16384, FP64 plans; one instance per call on p->cur / p->cur_scratch
+bool hx_ks_lat_applies(const hexl_ks_plan*, size_t nb);
+int hx_launch_keyswitch_lat(hexl_ks_plan*, u64* d_result, const u64* d_t_target);
 int hx_launch_multiply_relinearize(hexl_ks_plan*, u64* d_out, const u64* d_a, const u64* d_b, size_t batch);
 u32 hx_ks_x_loge();
 // index of coefficient held in register r of thread tid after a forward transform ("B layout")

@@ -28,6 +28,7 @@ struct KsArgsF {
     u32 L, K, nb;
     u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
     u32 overwrite;           // 1: `result` is written, not accumulated into (the host-pointer path: the HOST adds, fpga.cpp:441-475)
+    u32 skip;                // latency path: moduli of one size (hexl_ks_plan::x_skip) -> s' enters the mod-down transform un-reduced
 };
 
 __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswitch.hip: XCD-contiguous work ranges
@@ -276,6 +277,167 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     hxf::report_range(bad, a.range_flag);
 }
 
+// ---- latency path (round 4): a LONE keyswitch -- the SEAL bridge's only call shape (experimental/bridge-seal/tests/
+// fpga_context.h:13-16: set_worksize_KeySwitch(1)) -- in THREE dependent kernels instead of five. The dataflow is four transforms
+// deep whatever the kernel count (INTT -> NTT -> INTT_sp -> NTT); what can go is kernel boundaries and memory round trips:
+//   k_ksl_intt (b, d)        c_d = INTT(t_d) -> scratch; zeroes its share of the (integer) accumulator `prod`            step 1
+//   k_ksl_up   (b, slot, d)  NTT_{q_slot}(c_d mod q_slot) (slot == d: t_d itself, no transform), times key[d][slot][k], canonical,
+//                            ADDED into prod[k][slot] by 64-bit integer atomics: the sum over d of L <= 15 residues below 2^52
+//                            stays below 2^56, is exact in any order, and costs no extra kernel                       steps 2-3
+//   k_ksl_down (b, k, i)     every workgroup sums-down its own copy of the special limb: INTT_sp(prod[k][special]) stays in
+//                            registers (the inverse's output order is the forward's input order), then NTT_{q_i}, then the
+//                            mod-switch epilogue with prod[k][i] requested behind the cross-wave re-deal               steps 4-7
+// L + L(L+1) + 2L workgroups of one transform each (54 + ... at L = 6): the chip is mostly idle, latency is all that counts.
+// prod[.] mod q: the atomically accumulated word is below L q; four conditional subtractions bring it below q.
+template <int MAXBITS = 4>
+__device__ __forceinline__ u64 fold_below_q(u64 x, u64 q) {
+#pragma unroll
+    for (int s = MAXBITS - 1; s >= 0; --s) { const u64 m = q << s; x = x >= m ? x - m : x; }
+    return x;
+}
+
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_intt(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 item = blockIdx.x;                                  // b*L + d
+    const u32 L = a.L;
+    const u32 b = item / L, d = __builtin_amdgcn_readfirstlane(item - b * L);
+    // this workgroup's rows of the accumulator (2 (L+1) rows per instance, dealt round robin over its L workgroups)
+    u64* acc = reinterpret_cast<u64*>(a.prod) + size_t(b) * 2 * (L + 1) * G::N;
+    for (u32 row = d; row < 2 * (L + 1); row += L)
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) (acc + size_t(row) * G::N + G::idxA(r, 0))[u32(tid)] = 0;
+    const KsModF64 md = a.mods[d];
+    const double* tb = a.tables + size_t(d) * 4 * G::N;
+    const u64* src = a.t_target + size_t(item) * G::N;
+    const u64 qd = (u64)md.m.p;
+    double v[G::E];
+    hxf::RangeMask bad = 0;
+    const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);   // canonical words as they are
+    hxf::report_range(bad, a.range_flag);
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    double* dst = a.c + size_t(item) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) (dst + G::idxA(r, 0))[u32(tid)] = hxf::lift(v[r], md.m);
+}
+
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_up(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = blockIdx.x;                                  // (b*(L+1) + slot)*L + d
+    const u32 bs = item / L, d = item - bs * L;
+    const u32 b = bs / (L + 1), slot = __builtin_amdgcn_readfirstlane(bs - b * (L + 1));
+    const u32 i = slot < L ? slot : a.K - 1;
+    const KsModF64 md = a.mods[i];
+    const Mod m = md.m;
+    const double* k0 = a.keys + (size_t(d) * (L + 1) + slot) * 2 * G::N;        // key[d][slot][0], [1] follows; B order
+    double v[G::E], ka[G::E], kb[G::E];
+    auto request_keys = [&] {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { ka[r] = (k0 + r * G::T)[u32(tid)]; kb[r] = (k0 + G::N + r * G::T)[u32(tid)]; }
+    };
+    if (slot == d) {                                              // NTT(INTT(t_d) mod q_d) = t_d: no transform
+        const u64* src = a.t_target + (size_t(b) * L + d) * G::N;
+        const u32 tB = u32(G::idxB(0, tid));
+        u64 raw[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (src + G::idxB(r, 0))[tB];
+        request_keys();
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
+    } else {
+        const double* cd = a.c + (size_t(b) * L + d) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce((cd + G::idxA(r, 0))[u32(tid)], m);   // c_d mod q_i (intt1_redu.hpp:36-42)
+        const double* tb = a.tables + size_t(i) * 4 * G::N;
+        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, request_keys);          // |u| <= 2.14p; keys behind the cross-wave re-deal
+    }
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.prod) + size_t(b) * 2 * (L + 1) * G::N;
+    unsigned long long* p0 = acc + size_t(0 * (L + 1) + slot) * G::N;
+    unsigned long long* p1 = acc + size_t(1 * (L + 1) + slot) * G::N;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const u64 t0 = hxf::from_f64(hxf::lift(hxf::reduce(hxf::mul_mod(v[r], ka[r], m), m), m));
+        const u64 t1 = hxf::from_f64(hxf::lift(hxf::reduce(hxf::mul_mod(v[r], kb[r], m), m), m));
+        // relaxed, device scope, no return value: the order of the L additions does not matter for an integer sum
+        __hip_atomic_fetch_add(p0 + r * G::T + tid, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(p1 + r * G::T + tid, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int LOGN, int LOGE, int LAZY>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
+    using G = Geom<LOGN, LOGE>;
+    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    using WI = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x;
+    const u32 L = a.L;
+    const u32 item = blockIdx.x;                                  // (b*2 + k)*L + i
+    const u32 bk = item / L, i = __builtin_amdgcn_readfirstlane(item - bk * L);
+    const u32 b = bk >> 1, k = bk & 1;
+    const KsModF64 msp = a.mods[a.K - 1], md = a.mods[i];
+    const Mod m = md.m;
+    const u64* acc = reinterpret_cast<const u64*>(a.prod) + size_t(b) * 2 * (L + 1) * G::N;
+    const u64* psp = acc + size_t(k * (L + 1) + L) * G::N;        // accumulated special limb, B order
+    const u64* pi = acc + size_t(k * (L + 1) + i) * G::N;
+    double v[G::E];
+    {
+        const u64 qsp = (u64)msp.m.p;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52(fold_below_q<4>((psp + r * G::T)[u32(tid)], qsp));
+        const double* ts = a.tables + size_t(a.K - 1) * 4 * G::N;
+        WI::template inverse<true>(v, ldsd, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
+        // y = s' - floor(q_sp/2), the exact centred remainder (keyswitch_x.hip ksx_special_down; intt2_redu.hpp:25-51), A order
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            const double c = hxf::lift(v[r], msp.m);
+            v[r] = c > msp.half ? c - msp.m.p : c;
+        }
+    }
+    if (!a.skip) {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
+    }
+    const double* tb = a.tables + size_t(i) * 4 * G::N;
+    u64 praw[G::E];
+    W::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {     // |w| <= 2.14p
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) praw[r] = (pi + r * G::T)[u32(tid)];
+    });
+    const u64 qi = (u64)m.p;
+    u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;
+    const u32 tB = u32(G::idxB(0, tid));
+    if (a.overwrite) {                                            // host-pointer path: the output itself, canonical; the HOST adds
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            const double pv = hxf::reduce(hxf::to_f64_lt52(fold_below_q<4>(praw[r], qi)), m);
+            (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(hxf::reduce(hxf::mul_shoup(pv - v[r], md.msf, md.msf_p, m), m), m));
+        }
+        return;
+    }
+    u64 old[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) old[r] = (res + G::idxB(r, 0))[tB];
+    hxf::RangeMask bad = 0;
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        const double pv = hxf::reduce(hxf::to_f64_lt52(fold_below_q<4>(praw[r], qi)), m);
+        const double out = hxf::mul_shoup(pv - v[r], md.msf, md.msf_p, m);                          // ms.hpp:70-82
+        const double rr = hxf::reduce(hxf::to_f64_lt52_checked(old[r], qi, bad) + out, m);          // fpga.cpp:453-457
+        (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
+    }
+    hxf::report_range(bad, a.range_flag);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <class K>
 static int set_lds(K kern, size_t bytes) {
@@ -298,6 +460,30 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
         return rc0;
     hipStream_t st = p->cur;
     const u32 L = a.L, nb = a.nb;
+    // latency path (three kernels, above): a LONE keyswitch. Measured (tools/batch_sweep.py, N = 16384, device-resident): 70.3 us
+    // against 72.5 us for the five kernels at L = 6, 72.2 against 73.2 at L = 7 -- the four dependent transforms, ~14 us each for a
+    // lone workgroup (9-10 us of FP64 issue on ONE CU + a cold 128 KiB load + a kernel boundary), are what bounds it, not the
+    // kernel count; from two keyswitches up the five kernels win (their per-(slot, d) workgroups skip the redundant special-limb
+    // inverse: 73.5 against 78.3 us at two, 78.4 against 96.9 at four). HEXL_KS_LAT=0 turns it off, 1 forces it for every batch
+    // that takes this pipeline (tests).
+    // Not for N = 32768 (no registers for the key rows beside 64 data registers); timing runs (ev) keep the five-kernel path,
+    // whose stages the events bracket.
+    static const int lat = [] { const char* e = getenv("HEXL_KS_LAT"); return e ? atoi(e) : -1; }();
+    if constexpr (!G::HALF_ONLY)
+    if (!ev && stage_mask == 7 && L <= 15 && (lat == 1 || (lat != 0 && nb == 1))) {
+        static PerDeviceOnce once_l;
+        if (int rc0 = once_l.run(p->ctx->device, [] {
+                int rc = set_lds(k_ksl_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
+                if (!rc) rc = set_lds(k_ksl_up<LOGN, LOGE, LAZY>, G::LDS_USED);
+                if (!rc) rc = set_lds(k_ksl_down<LOGN, LOGE, LAZY>, G::LDS_USED);
+                return rc;
+            }))
+            return rc0;
+        hipLaunchKernelGGL((k_ksl_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksl_up<LOGN, LOGE, LAZY>), dim3(nb * (L + 1) * L), dim3(G::T), G::LDS_USED, st, a);
+        hipLaunchKernelGGL((k_ksl_down<LOGN, LOGE, LAZY>), dim3(nb * 2 * L), dim3(G::T), G::LDS_USED, st, a);
+        return (int)hipGetLastError();
+    }
     // one workgroup per input polynomial (all its transforms back to back) once that alone fills the chip twice;
     // below that one workgroup per transform, so that small batches still spread over the CUs
     const u32 cus = (u32)p->ctx->num_cu;
@@ -345,6 +531,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.range_flag = p->d_flag;
     a.overwrite = p->overwrite_result ? 1u : 0u;
+    a.skip = p->x_skip ? 1u : 0u;
     // LAZY template argument = forward reduction period (f64_arith.hpp): 3 when every modulus <= 2^51(1+2^-7), 6 / 12
     // for moduli <= 2^50 / 2^49 (N = 16384 only; the smaller transforms keep 3), 0 = strict
     if (p->f64_lazy) {

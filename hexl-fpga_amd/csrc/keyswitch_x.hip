@@ -67,6 +67,9 @@ using namespace hx;
 #ifndef KX_NEXT_AUX
 #define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
 #endif
+#ifndef KX_PRIO_MASK
+#define KX_PRIO_MASK 0  // k_ksx_main: waves whose number has a bit of this mask set run at s_setprio 1 (experiment)
+#endif
 #ifndef KX_KEY_AUX
 #define KX_KEY_AUX 0    // ... of the key loads
 #endif
@@ -435,7 +438,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 // PREF (KX_RMW_PREF builds, direct B-order read-modify-write only): the first PREF old result words are requested between the
 // transform's last re-deal and its partial pass (`before_last`), behind that pass's twiddles -- vector memory returns in order,
 // so nothing the pass waits for queues behind them -- instead of at the top of the epilogue, where all 16 waves of the workgroup
-// wait out an HBM latency together (~3 k cycles, twice per round). k = 0: 8 words (acc_1 is still live), k = 1: all 16.
+// wait out an HBM latency together (~3 k cycles, twice per round). KX_RMW_PREF bits: 1 = k = 0 requests 8 words early (acc_1 is
+// still live), 2 = k = 1 requests all 16, 4 = k = 1 requests 8. Measured (batch 8192, same box): 3 -> 204.1 k against 210.0 k
+// keyswitch/s for 0: the registers cost more than the latency.
 #ifndef KX_RMW_PREF
 #define KX_RMW_PREF 0
 #endif
@@ -551,6 +556,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0>;     // mod-up transforms (SKIP: canonical c_d as it is)
     constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
+#if KX_PRIO_MASK
+    // experiment: static priority for half of the waves of every SIMD (a workgroup's waves go to the SIMDs cyclically, so waves
+    // w, w + 4, w + 8, w + 12 share one): the favoured pair runs ahead and reaches its LDS re-deals while the other pair still has
+    // butterflies to issue, instead of all four stalling in the same phase
+    if ((threadIdx.x >> 6) & KX_PRIO_MASK) __builtin_amdgcn_s_setprio(1);
+#endif
     const u32 L = a.L;
     // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler
     // hoists out of the item loop costs more registers (34 spilled against 10) than the dispatch gaps cost time
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         KX_STAMP(4 * L + 0);
         const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W, -1, SKIP, (KX_RMW_PREF ? G::E / 2 : 0)>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
+        else ksx_down_round<G, W, -1, SKIP, ((KX_RMW_PREF & 1) ? G::E / 2 : 0)>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
         const double* nxt = a.s + (size_t(bc) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -649,7 +660,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* tb = a.tables + toff;
         const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W, -1, SKIP, (KX_RMW_PREF ? G::E : 0)>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
+        else ksx_down_round<G, W, -1, SKIP, ((KX_RMW_PREF & 2) ? G::E : (KX_RMW_PREF & 4) ? G::E / 2 : 0)>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
         KX_STAMP(4 * L + 8);
         hxf::report_range(bad, a.range_flag);
     }

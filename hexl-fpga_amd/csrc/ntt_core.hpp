@@ -122,20 +122,20 @@ struct Geom {
     static constexpr int LOGT = LOGN - LOGE;
     static constexpr int WB = LOGT < 6 ? LOGT : 6;         // thread-index bits that are lane bits
 
-    __device__ static __forceinline__ int pad(int idx) { return idx + (idx >> 4) + ((idx >> 9) << 4); }
-    __device__ static __forceinline__ int idxA(int r, int tid) { return r * T + tid; }
+    __host__ __device__ static constexpr int pad(int idx) { return idx + (idx >> 4) + ((idx >> 9) << 4); }
+    __host__ __device__ static constexpr int idxA(int r, int tid) { return r * T + tid; }
     // partial pass ("B order"): a thread owns NG groups of 2^KL adjacent coefficients. Lanes sit on index bits
     // [KL, KL+6), the group number above them and the wave number on the top bits -- the same top bits a wave
     // owns in every full pass with LO <= 6, so the re-deals between those passes never leave the wave.
-    __device__ static __forceinline__ int grpB(int grp, int tid) {            // coefficient index >> KL
+    __host__ __device__ static constexpr int grpB(int grp, int tid) {         // coefficient index >> KL
         return ((tid >> WB) << (LOGE - KL + WB)) + (grp << WB) + (tid & ((1 << WB) - 1));
     }
-    __device__ static __forceinline__ int idxB(int r, int tid) {
+    __host__ __device__ static constexpr int idxB(int r, int tid) {
         return (grpB(r >> KL, tid) << KL) + (r & ((1 << KL) - 1));
     }
     // full pass whose LOGE active index bits start at bit LO
     template <int LO>
-    __device__ static __forceinline__ int idxF(int r, int tid) {
+    __host__ __device__ static constexpr int idxF(int r, int tid) {
         return ((tid >> LO) << (LO + LOGE)) + (r << LO) + (tid & ((1 << LO) - 1));
     }
     // a re-deal between two ownership maps whose upper one is idxF<LO> moves data only inside a wave when the
@@ -255,6 +255,34 @@ __device__ __forceinline__ void wave_fence() {
 #ifndef HX_LDS_UNMERGED
 #define HX_LDS_UNMERGED 0
 #endif
+// HX_LDS_ASM_READ (experiment, 16-register geometries): the reads of a re-deal as sixteen hand-written ds_read_b64 -- which the
+// compiler cannot pair into ds_read2_b64 (8 LDS cycles per pair against 2 + 2) -- followed by two staged waits that hand the
+// values back to the compiler (it does not count LDS operations issued from inline assembly).
+#ifndef HX_LDS_ASM_READ
+#define HX_LDS_ASM_READ 0
+#endif
+template <class G, class ToIdx, int R, class V>
+__device__ __forceinline__ void lds_read_one_asm(V& dst, unsigned base, ToIdx to) {
+    constexpr int off = G::pad(to(R, 0)) * 8;
+    static_assert(off >= 0, "re-deal read offset");
+    const unsigned addr = base + unsigned(off & ~0xFFFF);        // the offset field holds 16 bits
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off & 0xFFFF));
+}
+template <class G, class ToIdx, class V>
+__device__ __forceinline__ void lds_read16_asm(V (&v)[16], const V* rd, ToIdx to) {
+    const unsigned base = (unsigned)(uintptr_t)rd;                // low half of a generic LDS address = the LDS offset
+    lds_read_one_asm<G, ToIdx, 0>(v[0], base, to);   lds_read_one_asm<G, ToIdx, 1>(v[1], base, to);
+    lds_read_one_asm<G, ToIdx, 2>(v[2], base, to);   lds_read_one_asm<G, ToIdx, 3>(v[3], base, to);
+    lds_read_one_asm<G, ToIdx, 4>(v[4], base, to);   lds_read_one_asm<G, ToIdx, 5>(v[5], base, to);
+    lds_read_one_asm<G, ToIdx, 6>(v[6], base, to);   lds_read_one_asm<G, ToIdx, 7>(v[7], base, to);
+    lds_read_one_asm<G, ToIdx, 8>(v[8], base, to);   lds_read_one_asm<G, ToIdx, 9>(v[9], base, to);
+    lds_read_one_asm<G, ToIdx, 10>(v[10], base, to); lds_read_one_asm<G, ToIdx, 11>(v[11], base, to);
+    lds_read_one_asm<G, ToIdx, 12>(v[12], base, to); lds_read_one_asm<G, ToIdx, 13>(v[13], base, to);
+    lds_read_one_asm<G, ToIdx, 14>(v[14], base, to); lds_read_one_asm<G, ToIdx, 15>(v[15], base, to);
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+
 template <class G, bool PRIVATE, bool LEAD, class V, class FromIdx, class ToIdx>
 __device__ __forceinline__ void redeal_x(V (&v)[G::E], V* lds, int tid, FromIdx from, ToIdx to) {
     V* const wr = lds + G::pad(from(0, tid));
@@ -268,10 +296,16 @@ __device__ __forceinline__ void redeal_x(V (&v)[G::E], V* lds, int tid, FromIdx 
     }
     if constexpr (PRIVATE) wave_fence();
     else __syncthreads();
+    if constexpr (HX_LDS_ASM_READ != 0 && G::E == 16 && sizeof(V) == 8) {
+        // the writes above are the compiler's own: wait for them here (s_waitcnt counts this wave's operations only; the barrier
+        // or the in-order LDS pipeline orders them against the reads below)
+        lds_read16_asm<G>(v, rd, to);
+    } else {
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) {
-        if constexpr ((HX_LDS_UNMERGED & 1) != 0) v[r] = *(const volatile V*)&rd[G::pad(to(r, 0))];
-        else v[r] = rd[G::pad(to(r, 0))];
+        for (int r = 0; r < G::E; ++r) {
+            if constexpr ((HX_LDS_UNMERGED & 1) != 0) v[r] = *(const volatile V*)&rd[G::pad(to(r, 0))];
+            else v[r] = rd[G::pad(to(r, 0))];
+        }
     }
     if constexpr (PRIVATE) wave_fence();
 }

@@ -534,6 +534,57 @@ uint64_t cb_keyswitch_timed(struct cb_plan* p, const uint64_t* t_src, const uint
     return total;
 }
 
+/* STREAM-style triad (a = b + s c on private, first-touched arrays of `mb` MiB each; 24 bytes moved per element) with the SAME
+ * thread placement as cb_keyswitch_timed: what the host's memory system gives this process at `threads` threads, in GB/s -- the
+ * yardstick for the keyswitch leg's parallel efficiency (the keys alone are a 29 MB stream per keyswitch and thread). */
+double cb_stream_triad(int threads, double seconds, uint64_t mb) {
+    static int cpus[4096];
+    int nphys = 0;
+    const int ncpu = cpu_order(cpus, 4096, &nphys);
+    const size_t words = (size_t)mb * (1 << 20) / 8;
+    double bytes = 0, worst = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+#pragma omp parallel num_threads(threads) reduction(+ : bytes) reduction(max : worst)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int t = 0, nt = 1;
+#endif
+        if (ncpu > 0) {
+            const int idx = nt <= nphys ? (int)((long)t * nphys / nt) : t % ncpu;
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[idx], &one);
+            sched_setaffinity(0, sizeof(one), &one);
+        }
+        double *a = (double*)malloc(words * 8), *b = (double*)malloc(words * 8), *c = (double*)malloc(words * 8);
+        for (size_t i = 0; i < words; i++) { a[i] = 0; b[i] = (double)i; c[i] = 1.0; }
+#pragma omp barrier
+        const double t0 = now_s();
+        double moved = 0;
+        do {
+            for (size_t i = 0; i < words; i++) a[i] = b[i] + 3.0 * c[i];
+            __asm__ volatile("" : : "r"(a) : "memory");
+            moved += 24.0 * (double)words;
+        } while (now_s() - t0 < seconds);
+        worst = now_s() - t0;
+        bytes = moved;
+        free(a); free(b); free(c);
+        if (ncpu > 0) {
+            cpu_set_t all;
+            CPU_ZERO(&all);
+            for (int i = 0; i < ncpu; i++) CPU_SET(cpus[i], &all);
+            sched_setaffinity(0, sizeof(all), &all);
+        }
+    }
+    return worst > 0 ? bytes / worst / 1e9 : 0.0;
+}
+
 /* batch of independent keyswitches, `threads` OpenMP threads (0 = all); returns the number of threads used */
 int cb_keyswitch_batch(const struct cb_plan* p, uint64_t* results, const uint64_t* t_targets, uint64_t batch, int threads) {
     const uint64_t n = p->n, L = p->L;

@@ -168,6 +168,8 @@ def cpu_baseline_lib(march: str = "native") -> ctypes.CDLL:
         L.cb_keyswitch_timed.restype = u64
         L.cb_keyswitch_timed.argtypes = [ctypes.c_void_p, P, P, u64, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int), P]
+        L.cb_stream_triad.restype = ctypes.c_double
+        L.cb_stream_triad.argtypes = [ctypes.c_int, ctypes.c_double, u64]
         L.cb_ntt_fwd_batch.restype = ctypes.c_int
         L.cb_ntt_fwd_batch.argtypes = [ctypes.c_void_p, u64, P, u64, ctypes.c_int]
         L.cb_max_threads.restype = ctypes.c_int; L.cb_max_threads.argtypes = []

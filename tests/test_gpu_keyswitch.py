@@ -454,6 +454,38 @@ def test_slot_major_kernels_in_every_tier(tier, n, L, K, nb):
     _alternative(dict(env, HEXL_KS_PIPE="3"), n, L, K, nb, moduli)
 
 
+@pytest.mark.parametrize("tier", list(TIERS))
+@pytest.mark.parametrize("L,K", [(6, 7), (7, 8), (3, 4), (1, 2), (5, 7), (15, 16)])
+def test_lone_keyswitch_latency_path(tier, L, K):
+    """keyswitch_lat.hip: a lone keyswitch at N = 16384 runs every transform as four quarter transforms on four compute units
+    (HEXL_KS_LAT=2 sends every instance of a batch down that path, one by one): same bits as the oracle in every tier"""
+    env, moduli = TIERS[tier]
+    if (L, K) in ((5, 7), (15, 16)) and tier not in ("skip_period3_51bit", "strict_just_below_2^52", "noskip_forced_period3_51bit"):
+        pytest.skip("shape covered in three tiers")
+    if K < 3 and "mixed_50_to_40bit" in tier:
+        pytest.skip("the mixed tier needs three key moduli")
+    _alternative(dict(env, HEXL_KS_LAT="2"), 16384, L, K, 3, moduli)
+
+
+def test_latency_paths_agree_on_one_keyswitch(hx, ctx, dev, orc):
+    """the default for one instance (quarter transforms), in-process, incl. accumulation into a non-zero result and a second call"""
+    n, L, K = 16384, 6, 7
+    case = KsCase(orc, n, L, K, seed=33)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    plan.set_keys(case.keys)
+    for b in range(3):
+        t, r = case.inputs(orc, b)
+        d_t, d_r = hx.as_i64(t).to(dev), hx.as_i64(r).to(dev)
+        plan.keyswitch(d_r, d_t, 1)
+        ctx.sync()
+        want = case.expected(orc, t, r)
+        assert np.array_equal(hx.to_u64(d_r), want), b
+        plan.keyswitch(d_r, d_t, 1)                               # accumulates again
+        ctx.sync()
+        assert np.array_equal(hx.to_u64(d_r), case.expected(orc, t, want)), b
+    plan.close()
+
+
 def _alternative(env, n, L, K, nb, moduli="None"):
     """`nb` instances (three distinct ones repeated) through the library in a child process with `env` set, against the oracle"""
     import os

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""batch_sweep.py -- keyswitch latency / throughput against batch size (N=16384, L=7, K=8), device-resident data."""
+"""batch_sweep.py [L = 7] [batches = 1,2,4,...] -- keyswitch latency / throughput against batch size (N=16384, K = L+1),
+device-resident data, the library's default path selection (HEXL_KS_LAT=0 in the environment turns the latency path off)."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -12,10 +13,12 @@ from ks_util import KsCase
 
 dev = torch.device("cuda:0")
 ctx = hx.Context(0)
-case = KsCase(orc, 16384, 7, 8, seed=1)
-plan = hx.KeySwitchPlan(ctx, 16384, 7, 8, 8, 2, case.moduli, case.modswitch)
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+BS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 1024]
+case = KsCase(orc, 16384, L, L + 1, seed=1)
+plan = hx.KeySwitchPlan(ctx, 16384, L, L + 1, L + 1, 2, case.moduli, case.modswitch)
 plan.set_keys(case.keys)
-for B in (1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 1024):
+for B in BS:
     d_t, d_r = bench.device_inputs(hx, orc, case, B, dev)
     for _ in range(3):
         plan.keyswitch(d_r, d_t, B)

@@ -39,7 +39,17 @@ struct PowerProbe {
         std::fclose(fp);
         return v;
     }
-    PowerProbe() {
+    explicit PowerProbe(const std::string& pci_bdf) {
+        // the hwmon of THIS GPU (the box has eight): /sys/bus/pci/devices/<domain:bus:dev.fn>/hwmon/hwmon*
+        if (!pci_bdf.empty()) {
+            glob_t g{};
+            if (!::glob(("/sys/bus/pci/devices/" + pci_bdf + "/hwmon/hwmon*").c_str(), 0, nullptr, &g) && g.gl_pathc) dir = g.gl_pathv[0];
+            globfree(&g);
+            if (!dir.empty()) return;
+        }
+        find_any();
+    }
+    void find_any() {
         // an amdgpu hwmon directory: it reports board power (power1_average or power1_input) AND the shader clock (freq1_input)
         for (const char* pat : {"/sys/class/drm/card*/device/hwmon/hwmon*", "/sys/bus/pci/devices/*/hwmon/hwmon*", "/sys/class/hwmon/hwmon*"}) {
             glob_t g{};
@@ -123,7 +133,10 @@ int main(int argc, char** argv) {
     }
     const bool power = getenv("HEXL_WORKLOAD_POWER") && atoi(getenv("HEXL_WORKLOAD_POWER")) == 1;
     if (power) { CK(hexl_keyswitch(plan, dr, dt, batch)); CK(hexl_ctx_sync(ctx)); }      // warm-up: scratch, clocks
-    PowerProbe probe;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, 0) != hipSuccess) bdf[0] = 0;
+    for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = char(*c - 'A' + 'a');     // sysfs names are lower case
+    PowerProbe probe(bdf);
     if (power) probe.start();
     const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < reps; ++r) CK(hexl_keyswitch(plan, dr, dt, batch));
