@@ -142,7 +142,7 @@ bool hx_ks_x_applies(const hexl_ks_plan*, size_t nb);
 bool hx_ks_can_overwrite(const hexl_ks_plan*, size_t nb);
 // the lone-keyswitch latency path (keyswitch_lat.hip): N = 16384, FP64 plans; one instance per call on p->cur / p->cur_scratch
 bool hx_ks_lat_applies(const hexl_ks_plan*, size_t nb);
-int hx_launch_keyswitch_lat(hexl_ks_plan*, u64* d_result, const u64* d_t_target);
+int hx_launch_keyswitch_lat(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb);
 int hx_launch_multiply_relinearize(hexl_ks_plan*, u64* d_out, const u64* d_a, const u64* d_b, size_t batch);
 u32 hx_ks_x_loge();
 // index of coefficient held in register r of thread tid after a forward transform ("B layout")

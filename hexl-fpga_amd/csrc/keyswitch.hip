@@ -526,8 +526,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
             continue;
         }
         if (p->use_f64 && !ev && stage_mask == 7 && hx_ks_lat_applies(p, nb)) {     // a lone keyswitch: every transform cut in four
-            for (size_t b = 0; b < nb; ++b)
-                if ((rc = hx_launch_keyswitch_lat(p, d_result + (b0 + b) * 2 * L * n, d_t_target + (b0 + b) * L * n))) return rc;
+            if ((rc = hx_launch_keyswitch_lat(p, d_result + b0 * 2 * L * n, d_t_target + b0 * L * n, nb))) return rc;
             continue;
         }
         if (p->use_f64) {

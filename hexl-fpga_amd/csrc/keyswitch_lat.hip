@@ -38,11 +38,12 @@ struct KsArgsQ {
     const KsModF64* mods;    // [K]
     const double* tables;    // [K][4][n]: w, w/p, inverse w (first entry at index 1), inverse w/p
     const double* keys;      // [L][L+1][2][n] centred, NATURAL order
-    double* sub;             // [L][n]   the four sub-inverses of t_target[d], natural order inside each quarter
-    double* subsp;           // [2][n]   the same for the accumulated special limb
-    unsigned long long* prod;  // [2][L+1][n] integer accumulators, natural order
-    const u64* t_target;     // [L][n]
-    u64* result;             // [2][L][n]
+    // per instance b = blockIdx.y (a handful at most):
+    double* sub;             // [b][L][n]   the four sub-inverses of t_target[d], natural order inside each quarter
+    double* subsp;           // [b][2][n]   the same for the accumulated special limb
+    unsigned long long* prod;  // [b][2][L+1][n] integer accumulators, natural order
+    const u64* t_target;     // [b][L][n]
+    u64* result;             // [b][2][L][n]
     u32 L, K;
     u32* range_flag;
     u32 overwrite, skip;     // as in keyswitch_f64.hip
@@ -52,6 +53,9 @@ struct KsArgsQ {
 // the wave's own independent work. Tell the backend that occupancy is not a goal here (it otherwise schedules for few registers,
 // i.e. one chain after the other).
 #define KSQ_ILP __attribute__((amdgpu_waves_per_eu(1, 2)))
+#ifndef KSQ_DEFAULT_MAX_PAIRS
+#define KSQ_DEFAULT_MAX_PAIRS 128    // batches with at most this many (slot, d) pairs take the quarter-transform path by default
+#endif
 
 constexpr int QLOGN = 14, QLOGM = 12, QLOGE = 4;
 using GQ = Geom<QLOGM, QLOGE>;                                   // 256 threads x 16 coefficients, three full passes
@@ -133,14 +137,15 @@ template <int LAZY>
 __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_intt(KsArgsQ a) {
     extern __shared__ __attribute__((aligned(16))) double ldsq[];
     const int tid = threadIdx.x;
-    const u32 d = blockIdx.x >> 2, q = blockIdx.x & 3, L = a.L;
-    // zero this workgroup's share of the integer accumulators: 2 (L+1) rows of n words, dealt over the 4 L workgroups by quarter rows
+    const u32 d = blockIdx.x >> 2, q = blockIdx.x & 3, L = a.L, b = blockIdx.y;
+    // zero this workgroup's share of the instance's integer accumulators: 2 (L+1) rows of n words, dealt over the 4 L workgroups by quarter rows
+    unsigned long long* const pb = a.prod + size_t(b) * 2 * (L + 1) * (1 << QLOGN);
     for (u32 row = blockIdx.x; row < 2 * (L + 1) * 4; row += 4 * L)
 #pragma unroll
-        for (int r = 0; r < GQ::E; ++r) (a.prod + size_t(row) * QM + GQ::idxA(r, 0))[u32(tid)] = 0;
+        for (int r = 0; r < GQ::E; ++r) (pb + size_t(row) * QM + GQ::idxA(r, 0))[u32(tid)] = 0;
     const KsModF64 md = a.mods[d];
     const u64 qd = (u64)md.m.p;
-    const u64* src = a.t_target + size_t(d) * (1 << QLOGN) + size_t(q) * QM;
+    const u64* src = a.t_target + (size_t(b) * L + d) * (1 << QLOGN) + size_t(q) * QM;
     double v[GQ::E];
     hxf::RangeMask bad = 0;
 #pragma unroll
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_intt(KsArgsQ a) {
     a_to_b(v, ldsq, tid);
     const double* tb = a.tables + size_t(d) * 4 * (1 << QLOGN);
     WgSubNtt<LAZY>::template inv_pass<0>(v, ldsq, tid, q, tb + 2 * (1 << QLOGN), md.m);
-    double* dst = a.sub + size_t(d) * (1 << QLOGN) + size_t(q) * QM;
+    double* dst = a.sub + (size_t(b) * L + d) * (1 << QLOGN) + size_t(q) * QM;
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) (dst + GQ::idxA(r, 0))[u32(tid)] = v[r];
 }
@@ -159,7 +164,7 @@ template <int LAZY>
 __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_up(KsArgsQ a) {
     extern __shared__ __attribute__((aligned(16))) double ldsq[];
     const int tid = threadIdx.x;
-    const u32 L = a.L;
+    const u32 L = a.L, b = blockIdx.y;
     const u32 q = blockIdx.x & 3, sd = blockIdx.x >> 2;
     const u32 slot = sd / L, d = sd - slot * L;
     const u32 i = slot < L ? slot : a.K - 1;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_up(KsArgsQ a) {
         for (int r = 0; r < GQ::E; ++r) { ka[r] = (k0 + GQ::idxA(r, 0))[u32(tid)]; kb[r] = (k0 + N + GQ::idxA(r, 0))[u32(tid)]; }
     };
     if (slot == d) {                                              // NTT(INTT(t_d) mod q_d) = t_d
-        const u64* src = a.t_target + size_t(d) * N + size_t(q) * QM;
+        const u64* src = a.t_target + (size_t(b) * L + d) * N + size_t(q) * QM;
         u64 raw[GQ::E];
 #pragma unroll
         for (int r = 0; r < GQ::E; ++r) raw[r] = (src + GQ::idxA(r, 0))[u32(tid)];
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_up(KsArgsQ a) {
         for (int r = 0; r < GQ::E; ++r) v[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
     } else {
         const KsModF64 md = a.mods[d];
-        const double* sb = a.sub + size_t(d) * N;
+        const double* sb = a.sub + (size_t(b) * L + d) * N;
         const double* tbd = a.tables + size_t(d) * 4 * N;
         const double* tbi = a.tables + size_t(i) * 4 * N;
         double sv[GQ::E][4];
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_up(KsArgsQ a) {
         WgSubNtt<LAZY>::template fwd_pass<0>(v, ldsq, tid, q, tbi, m);
         b_to_a(v, ldsq, tid);
     }
-    unsigned long long* p0 = a.prod + size_t(0 * (L + 1) + slot) * N + size_t(q) * QM;
-    unsigned long long* p1 = a.prod + size_t(1 * (L + 1) + slot) * N + size_t(q) * QM;
+    unsigned long long* p0 = a.prod + (size_t(b) * 2 * (L + 1) + slot) * N + size_t(q) * QM;
+    unsigned long long* p1 = p0 + size_t(L + 1) * N;
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) {
         const u64 t0 = hxf::from_f64(hxf::lift(hxf::reduce(hxf::mul_mod(v[r], ka[r], m), m), m));
@@ -222,18 +227,18 @@ template <int LAZY>
 __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_intt_sp(KsArgsQ a) {
     extern __shared__ __attribute__((aligned(16))) double ldsq[];
     const int tid = threadIdx.x;
-    const u32 k = blockIdx.x >> 2, q = blockIdx.x & 3, L = a.L;
+    const u32 k = blockIdx.x >> 2, q = blockIdx.x & 3, L = a.L, b = blockIdx.y;
     constexpr size_t N = size_t(1) << QLOGN;
     const KsModF64 msp = a.mods[a.K - 1];
     const u64 qsp = (u64)msp.m.p;
-    const unsigned long long* src = a.prod + size_t(k * (L + 1) + L) * N + size_t(q) * QM;
+    const unsigned long long* src = a.prod + (size_t(b) * 2 * (L + 1) + k * (L + 1) + L) * N + size_t(q) * QM;
     double v[GQ::E];
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) v[r] = hxf::to_f64_lt52(fold_below_q4((src + GQ::idxA(r, 0))[u32(tid)], qsp));
     a_to_b(v, ldsq, tid);
     const double* ts = a.tables + size_t(a.K - 1) * 4 * N;
     WgSubNtt<LAZY>::template inv_pass<0>(v, ldsq, tid, q, ts + 2 * N, msp.m);
-    double* dst = a.subsp + size_t(k) * N + size_t(q) * QM;
+    double* dst = a.subsp + (size_t(b) * 2 + k) * N + size_t(q) * QM;
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) (dst + GQ::idxA(r, 0))[u32(tid)] = v[r];
 }
@@ -243,17 +248,17 @@ template <int LAZY>
 __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
     extern __shared__ __attribute__((aligned(16))) double ldsq[];
     const int tid = threadIdx.x;
-    const u32 L = a.L;
+    const u32 L = a.L, b = blockIdx.y;
     const u32 q = blockIdx.x & 3, ki = blockIdx.x >> 2;
     const u32 k = ki / L, i = ki - k * L;
     constexpr size_t N = size_t(1) << QLOGN;
     const KsModF64 msp = a.mods[a.K - 1], md = a.mods[i];
     const Mod m = md.m;
-    const double* sb = a.subsp + size_t(k) * N;
+    const double* sb = a.subsp + (size_t(b) * 2 + k) * N;
     const double* ts = a.tables + size_t(a.K - 1) * 4 * N;
     const double* tb = a.tables + size_t(i) * 4 * N;
-    const unsigned long long* pi = a.prod + size_t(k * (L + 1) + i) * N + size_t(q) * QM;
-    u64* res = a.result + (size_t(k) * L + i) * N + size_t(q) * QM;
+    const unsigned long long* pi = a.prod + (size_t(b) * 2 * (L + 1) + k * (L + 1) + i) * N + size_t(q) * QM;
+    u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * N + size_t(q) * QM;
     u64 praw[GQ::E], old[GQ::E];
     double v[GQ::E];
     double sv[GQ::E][4];
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
 
 // ---------------------------------------------------------------------------------------------
 template <int LAZY>
-static int run_lat(hexl_ks_plan* p, const KsArgsQ& a) {
+static int run_lat(hexl_ks_plan* p, const KsArgsQ& a, u32 nb) {
     static PerDeviceOnce once;
     constexpr size_t lds = GQ::LDS_USED;
     if (int rc0 = once.run(p->ctx->device, [] {
@@ -313,19 +318,26 @@ static int run_lat(hexl_ks_plan* p, const KsArgsQ& a) {
         return rc0;
     hipStream_t st = p->cur;
     const u32 L = a.L;
-    hipLaunchKernelGGL((k_ksq_intt<LAZY>), dim3(4 * L), dim3(GQ::T), lds, st, a);
-    hipLaunchKernelGGL((k_ksq_up<LAZY>), dim3(4 * L * (L + 1)), dim3(GQ::T), lds, st, a);
-    hipLaunchKernelGGL((k_ksq_intt_sp<LAZY>), dim3(8), dim3(GQ::T), lds, st, a);
-    hipLaunchKernelGGL((k_ksq_down<LAZY>), dim3(8 * L), dim3(GQ::T), lds, st, a);
+    hipLaunchKernelGGL((k_ksq_intt<LAZY>), dim3(4 * L, nb), dim3(GQ::T), lds, st, a);
+    hipLaunchKernelGGL((k_ksq_up<LAZY>), dim3(4 * L * (L + 1), nb), dim3(GQ::T), lds, st, a);
+    hipLaunchKernelGGL((k_ksq_intt_sp<LAZY>), dim3(8, nb), dim3(GQ::T), lds, st, a);
+    hipLaunchKernelGGL((k_ksq_down<LAZY>), dim3(8 * L, nb), dim3(GQ::T), lds, st, a);
     return (int)hipGetLastError();
 }
 
-// one keyswitch (N = 16384, FP64 plan with natural-order keys) on the caller's stream; scratch = the plan's current lane
+// a few keyswitches (N = 16384, FP64 plan with natural-order keys) on p->cur; scratch = the plan's current lane (nb <= p->cap).
+// HEXL_KS_LAT: 0 = off, 1 = the three-kernel path of keyswitch_f64.hip instead, 2 = this path for EVERY batch that fits a scratch
+// chunk (tests), HEXL_KS_LAT_MAX = largest batch that takes it by default.
 bool hx_ks_lat_applies(const hexl_ks_plan* p, size_t nb) {
     static const int lat = [] { const char* e = getenv("HEXL_KS_LAT"); return e ? atoi(e) : -1; }();
-    return p->use_f64 && p->logn == QLOGN && p->d_keys_nat && p->L <= 15 && lat != 0 && lat != 1 && (nb == 1 || lat == 2);
+    static const long most = [] { const char* e = getenv("HEXL_KS_LAT_MAX"); return e ? atol(e) : -1L; }();
+    // default: as long as the (slot, d) pairs of the batch are at most KSQ_DEFAULT_MAX_PAIRS -- measured (tools/batch_sweep.py, us per
+    // launch, this path / the five kernels): L = 6: 49.4 / 71.4 at one keyswitch, 59.7 / 73.8 at two, 67.2 / 76.5 at three, 80.2 / 78.5
+    // at four; L = 7: 54.6 / 73.7, 67.6 / 76.3, 79.9 / 78.4 at three
+    const bool small = most >= 0 ? nb <= (size_t)most : nb * p->L * (p->L + 1) <= size_t(KSQ_DEFAULT_MAX_PAIRS);
+    return p->use_f64 && p->logn == QLOGN && p->d_keys_nat && p->L <= 15 && lat != 0 && lat != 1 && (small || lat == 2);
 }
-int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_target) {
+int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb) {
     const size_t n = p->n, L = p->L;
     KsArgsQ a;
     a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_nat;
@@ -342,9 +354,9 @@ int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.overwrite = p->overwrite_result ? 1u : 0u;
     a.skip = p->x_skip ? 1u : 0u;
     switch (p->f64_lazy) {
-        case 12: return run_lat<12>(p, a);
-        case 6:  return run_lat<6>(p, a);
-        case 3:  return run_lat<3>(p, a);
-        default: return run_lat<0>(p, a);
+        case 12: return run_lat<12>(p, a, (u32)nb);
+        case 6:  return run_lat<6>(p, a, (u32)nb);
+        case 3:  return run_lat<3>(p, a, (u32)nb);
+        default: return run_lat<0>(p, a, (u32)nb);
     }
 }
