@@ -16,7 +16,7 @@ static double rnd(unsigned long long& s, double p) {   // centred pseudo-random 
 
 int main(int argc, char** argv) {
 #ifndef KX_LOGE
-#define KX_LOGE 5
+#define KX_LOGE 4      // the production geometry (16 coefficients x 1024 threads); 5 = 32 x 512
 #endif
     using G = Geom<14, KX_LOGE>;
     const u32 nb = argc > 1 ? atoi(argv[1]) : 256, L = argc > 2 ? atoi(argv[2]) : 7, K = L + 1, N = G::N;
@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dtt, t.data(), t.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dres, res.data(), res.size() * 8, hipMemcpyHostToDevice);
     a.mods = dm; a.tables = dt; a.keys = dk; a.c = dc; a.s = ds; a.t_target = dtt; a.result = dres;
-    a.L = L; a.K = K; a.nb = nb; a.stamps = dst; a.key_stride = 2u << 14; a.range_flag = dflag;
+    a.L = L; a.K = K; a.nb = nb; a.stamps = dst; a.key_stride = 2u << 14; a.alias = 0; a.range_flag = dflag;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto kin = k_ksx_intt<14, KX_LOGE, 3>;
     hipFuncSetAttribute((const void*)kin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
@@ -68,8 +68,9 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep) printf("==== k_ksx_intt: grid %u, %.1f us = %.1f us per round of 256 workgroups\n", nb * L, ms * 1e3, ms * 1e3 / ((nb * L + 255) / 256));
     }
-    auto ksp = k_ksx_special<14, KX_LOGE, 3>;
-    auto kmn = k_ksx_main<14, KX_LOGE, 3>;
+    // the kernels bench.py's workload runs: lazy period 3, SKIP (moduli of one size: no range reduction of c_d / s')
+    auto ksp = k_ksx_special<14, KX_LOGE, 3, true>;
+    auto kmn = k_ksx_main<14, KX_LOGE, 3, false, true>;
     hipFuncSetAttribute((const void*)ksp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
     hipFuncSetAttribute((const void*)kmn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
     const int W = G::T / 64;

@@ -10,8 +10,14 @@ rm -rf $OUT/kt $OUT/pmc
 # one lane: the default schedule alternates chunks between two streams, whose kernels then overlap and stretch each
 # other's durations in the trace; one lane gives per-kernel durations that add up (bench.py's stage timers are one-lane too)
 HEXL_KS_ONE_LANE=1 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu --no-pmc > $OUT/bench_under_trace.log 2>&1
-python3 $R/tools/rocprof_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_trace.txt 2>&1
-python3 $R/tools/overlap.py $(find $OUT/kt -name "*.db" | head -1) >> $OUT/kernel_trace.txt 2>&1
+# bench.py starts child processes (tests/cpp/bench_cxx_api for the end-to-end leg), each with its own database: the largest one is bench.py's
+DB=$(find $OUT/kt -name "*.db" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2-)
+python3 $R/tools/rocprof_summary.py $DB > $OUT/kernel_trace.txt 2>&1
+python3 $R/tools/overlap.py $DB >> $OUT/kernel_trace.txt 2>&1
+for other in $(find $OUT/kt -name "*.db" | grep -v "$DB"); do
+  echo "" >> $OUT/kernel_trace.txt; echo "# child process $(basename $other) (tests/cpp/bench_cxx_api: the lone-keyswitch latency path, keyswitch_lat.hip)" >> $OUT/kernel_trace.txt
+  python3 $R/tools/rocprof_summary.py $other 2>&1 | head -8 >> $OUT/kernel_trace.txt
+done
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
