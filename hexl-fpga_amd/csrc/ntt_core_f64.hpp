@@ -25,13 +25,16 @@ typedef const __attribute__((address_space(4))) double* ctw_t;
 // alone the compiler requests all 2^u twiddles of a stage (all 31 of a five-stage pass) up front: ~60 registers that
 // a kernel holding 128 accumulator registers does not have (it spilled a quarter of the accumulators for good).
 // SHIFT: phase of the reduction schedule (f64_arith.hpp lazy_fwd_reduce_after; 1 = un-centred inputs taken as they are)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0, int SHIFT = 0>
+// NORED: global stage whose PERIODIC reduction is dropped (0 = none): on the shifted schedule the last stage of a 2^14-point
+// transform is a periodic reduction point ((14 + 1) % 3 == 0); a transform whose consumer takes an un-reduced tail (FINAL = false)
+// drops it and hands over three un-reduced stages, 3.45p, instead (f64_arith.hpp)
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0, int SHIFT = 0, int NORED = 0>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT);
+        const bool red = !LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED);
         constexpr int TFR = TF > 0 ? TF : 1;
         const bool ring = TF > 0 && !UNI && (1 << u) > TF;
         double Wq[TFR];
@@ -60,11 +63,11 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 }
 
 // the same K stages with their 2^K - 1 twiddles already in registers (tw[(1 << u) - 1 + j] = stage u, sub-block j)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0, int NORED = 0>
 __device__ __forceinline__ void fwd_stages_f64_tw(double (&v)[E], const double (&tw)[(1 << K) - 1], const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT);
+        const bool red = !LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = tw[(1 << u) - 1 + j];
@@ -222,6 +225,9 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
 // (194 k -> 200 k keyswitch/s); PRE >= 10: the per-lane full pass requests its early stages' twiddles up front as well
 // (fwd_stages_f64_ahead: -> 202 k). Left alone, a kernel that holds 96 data registers gets every twiddle load of that pass right in
 // front of its first use with an s_waitcnt vmcnt(0) behind it -- eight fully exposed L2 latencies per transform.
+#ifndef HX_KEEP_LAST_REDUCE
+#define HX_KEEP_LAST_REDUCE 0   // 1: A/B variant that keeps the periodic reduction on the last stage of the shifted schedule
+#endif
 // FSHIFT: phase of the forward reduction schedule (1: un-centred inputs, f64_arith.hpp); NOWP: inverse transforms without
 // the w/p table
 template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false>
@@ -284,14 +290,16 @@ struct WgNttF64 {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = u32(G::grpB(GRP, tid));
             // LOGN = 0 tells the stage loop that no stage is the last one
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF, FSHIFT>(v, Gbits, w, wp, m);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF, FSHIFT,
+                           (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? LOGN : 0>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }
     template <int GRP, bool FINAL = true>
     __device__ static __forceinline__ void fwd_last_tw(double (&v)[E], const double (&tl)[G::NG][(1 << G::KL) - 1], const Mod m) {
         if constexpr (GRP < G::NG) {
-            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, FSHIFT>(v, tl[GRP], m);
+            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, FSHIFT,
+                              (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? LOGN : 0>(v, tl[GRP], m);
             fwd_last_tw<GRP + 1, FINAL>(v, tl, m);
         }
     }

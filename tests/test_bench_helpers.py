@@ -29,7 +29,7 @@ def test_pmc_passes_merge_into_per_keyswitch_figures():
     # FETCH_SIZE in KiB, doubled (gfx950 under-reports these kernels' reads by 2x); WRITE_SIZE in KiB as is
     want = ((1.0e6 * 2 + 5.0e5) + (2.0e5 * 2 + 2.0e5)) * 1024 / batch
     assert abs(d["traffic_bytes_per_keyswitch"] - want) < 1e-6
-    assert abs(d["shader_clock_ghz"] - 2.0) < 1e-9                      # (2.0e6 + 2.0e5) cycles per XCD over 1100 us
+    assert abs(d["shader_clock_ghz"] - 2.0) < 1e-9                      # the longest kernel's: 2.0e6 cycles per XCD over 1000 us
     k = d["kernels"]["k_ksx_main<14, 4, 3, false>"]
     assert abs(k["fp64_issue_frac"] - 3.6e8 * 4 / 1024 / 2.0e3 / 1000.0) < 1e-9
     assert abs(sum(k["wave_time_split"].values()) - 1.0) < 1e-9
@@ -54,3 +54,16 @@ def test_alu_fraction_uses_the_timed_regions_clock():
     assert a["achieved_frac"] < a["achieved_frac_at_pmc_pass_clock"] and a["shader_clock_ghz"] == 2.153
     b = bench.alu_block(vw, cus, us, timed_sclk_mhz=None, pmc_clock_ghz=2.042)   # no hwmon: falls back, and says so
     assert b["achieved_frac"] == b["achieved_frac_at_pmc_pass_clock"] and "PMC" in b["shader_clock_source"]
+
+
+def test_short_kernels_do_not_get_their_own_clock():
+    """GRBM_GUI_ACTIVE of a short dispatch also covers the set-up around it (round 4: 3.02 "GHz" for the 165 us k_ksx_special made its
+    issue fraction read 0.44): per-kernel clocks outside (0.5, 2.45) GHz fall back to the longest kernel's"""
+    import pmc_summary
+    vals = {"k_ksx_main<14, 4, 3, false, true>": {"SQ_INSTS_VALU": 3.4e8, "GRBM_GUI_ACTIVE": 8 * 2.1e6},
+            "k_ksx_special<14, 4, 3, true>": {"SQ_INSTS_VALU": 5.58e7, "GRBM_GUI_ACTIVE": 4.0e6}}
+    dur = {"k_ksx_main<14, 4, 3, false, true>": [1000.0], "k_ksx_special<14, 4, 3, true>": [165.5]}
+    d = pmc_summary.derive(vals, dur, 256, 7, simds=1024)
+    sp = d["kernels"]["k_ksx_special<14, 4, 3, true>"]
+    assert abs(d["shader_clock_ghz"] - 2.1) < 1e-9 and abs(sp["shader_clock_ghz"] - 2.1) < 1e-9 and sp["shader_clock_ghz_raw"] > 3.0
+    assert abs(sp["fp64_issue_frac"] - 5.58e7 * 4 / 1024 / 2.1e3 / 165.5) < 1e-9 and 0.6 < sp["fp64_issue_frac"] < 0.65

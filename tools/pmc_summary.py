@@ -61,13 +61,23 @@ def derive(vals, dur, batch, L, simds=1024):
             wc = v["SQ_WAVE_CYCLES"]
             e["wave_time_split"] = {"active": v["SQ_ACTIVE_INST_ANY"] / wc, "issue_stall": v["SQ_WAIT_INST_ANY"] / wc,
                                     "waitcnt_barrier": v["SQ_WAIT_ANY"] / wc}
-        if "valu_wave_instructions" in e and "shader_clock_ghz" in e:
-            # time the kernel's VALU instructions need at 4 cycles each if no SIMD ever idled / its measured duration
-            e["fp64_issue_frac"] = e["valu_wave_instructions"] * 4 / simds / (e["shader_clock_ghz"] * 1e3) / d
         out["kernels"][k] = e
     out["traffic_bytes_per_keyswitch"] = tot_bytes / batch if have_bytes else None
     out["valu_wave_instructions_per_keyswitch"] = tot_valu / batch if have_valu else None
-    out["shader_clock_ghz"] = clk_num / clk_den if clk_den else None
+    # The clock: GRBM_GUI_ACTIVE / 8 XCDs / duration of the LONGEST kernel. For a short dispatch the counter also covers the set-up
+    # around it (round 4: k_ksx_special, 165 us, read "3.02 GHz" on a 2.4 GHz part, which made its issue fraction read 0.44 instead of
+    # 0.63); the ~1 ms k_ksx_main dispatch is long enough. Per-kernel clocks outside (0.5, 2.45) GHz are replaced by it.
+    clocks = {k: e["shader_clock_ghz"] for k, e in out["kernels"].items() if "shader_clock_ghz" in e}
+    longest = max(clocks, key=lambda k: out["kernels"][k]["avg_us_under_pmc"]) if clocks else None
+    out["shader_clock_ghz"] = clocks[longest] if longest else (clk_num / clk_den if clk_den else None)
+    for k, e in out["kernels"].items():
+        if "valu_wave_instructions" in e and out["shader_clock_ghz"]:
+            c = e.get("shader_clock_ghz")
+            if c is None or not (0.5 < c < 2.45):
+                e["shader_clock_ghz_raw"], c = c, out["shader_clock_ghz"]
+                e["shader_clock_ghz"] = c
+            # time the kernel's VALU instructions need at 4 cycles each if no SIMD ever idled / its measured duration
+            e["fp64_issue_frac"] = e["valu_wave_instructions"] * 4 / simds / (c * 1e3) / e["avg_us_under_pmc"]
     out["alg_bytes_per_keyswitch"] = (L + 4 * L) * N * 8
     return out
 
@@ -96,8 +106,11 @@ def main():
         if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
             print("    -> VALU instructions per wave: %.0f" % (v["SQ_INSTS_VALU"] / v["SQ_WAVES"]))
         if "SQ_INSTS_VALU" in v and clk:
-            print("    -> FP64-issue fraction: %.3f (VALU wave-instructions x 4 cycles / 1024 SIMDs / clock / duration)" % (
-                v["SQ_INSTS_VALU"] * 4 / 1024 / (clk * 1e3) / d))
+            if not (0.5 < clk < 2.45):
+                print("    -> (that clock is not credible for a %.0f us dispatch -- the counter covers the set-up around it; see the summary below)" % d)
+            else:
+                print("    -> FP64-issue fraction: %.3f (VALU wave-instructions x 4 cycles / 1024 SIMDs / clock / duration)" % (
+                    v["SQ_INSTS_VALU"] * 4 / 1024 / (clk * 1e3) / d))
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             rd, wr = v["FETCH_SIZE"] * 1024 * 2, v["WRITE_SIZE"] * 1024
             hit = ""
@@ -105,6 +118,10 @@ def main():
                 hit = "; L2 hit rate %.1f%%" % (100 * v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]))
             print("    -> L2-miss-side bytes per dispatch: read %.3f GB (x2-corrected), write %.3f GB%s" % (rd / 1e9, wr / 1e9, hit))
     d = derive(vals, dur, batch, L)
+    for k, e in d["kernels"].items():
+        if "fp64_issue_frac" in e:
+            print("# %s: FP64-issue fraction %.3f at %.2f GHz%s" % (k, e["fp64_issue_frac"], e["shader_clock_ghz"],
+                  " (clock of the longest kernel; its own GRBM reading was %.2f GHz)" % e["shader_clock_ghz_raw"] if "shader_clock_ghz_raw" in e else ""))
     alg = d["alg_bytes_per_keyswitch"]
     if d["traffic_bytes_per_keyswitch"]:
         print(f"\n# keyswitch pipeline: measured L2-miss-side traffic {d['traffic_bytes_per_keyswitch'] / 1e6:.2f} MB per keyswitch "
