@@ -334,7 +334,8 @@ bool hx_ks_lat_applies(const hexl_ks_plan* p, size_t nb) {
     // default: as long as the (slot, d) pairs of the batch are at most KSQ_DEFAULT_MAX_PAIRS -- measured (tools/batch_sweep.py, us per
     // launch, this path / the five kernels): L = 6: 49.4 / 71.4 at one keyswitch, 59.7 / 73.8 at two, 67.2 / 76.5 at three, 80.2 / 78.5
     // at four; L = 7: 54.6 / 73.7, 67.6 / 76.3, 79.9 / 78.4 at three
-    const bool small = most >= 0 ? nb <= (size_t)most : nb * p->L * (p->L + 1) <= size_t(KSQ_DEFAULT_MAX_PAIRS);
+    // (and at most eight instances: the rule was measured at L = 6 and 7; short key chains would otherwise send dozens of instances here)
+    const bool small = most >= 0 ? nb <= (size_t)most : (nb <= 8 && nb * p->L * (p->L + 1) <= size_t(KSQ_DEFAULT_MAX_PAIRS));
     return p->use_f64 && p->logn == QLOGN && p->d_keys_nat && p->L <= 15 && lat != 0 && lat != 1 && (small || lat == 2);
 }
 int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb) {

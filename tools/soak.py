@@ -16,7 +16,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 dev = torch.device("cuda:0")
 ctx = hx.Context(0)
 bad = 0
-for (L, K, B) in ((7, 8, 512), (6, 7, 300), (3, 4, 40)):
+# (the last two shapes take the quarter-transform latency path, keyswitch_lat.hip: one and three instances, integer atomics)
+for (L, K, B) in ((7, 8, 512), (6, 7, 300), (3, 4, 40), (6, 7, 1), (6, 7, 3), (7, 8, 2)):
     case = KsCase(orc, 16384, L, K, seed=L)
     plan = hx.KeySwitchPlan(ctx, 16384, L, K, K, 2, case.moduli, case.modswitch)
     plan.set_keys(case.keys)
