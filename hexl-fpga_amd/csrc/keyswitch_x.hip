@@ -177,7 +177,9 @@ __device__ __forceinline__ void load_natural_to_B(double (&v)[G::E], const u64* 
 // (Requesting the next input in one burst behind the last key instead measured the same within noise at four waves per
 // SIMD: 10.4 k against 9.5 k cycles per multiply-accumulate in the timeline tool.)
 // Ring depth: three pairs measured best (192 k keyswitch/s against 181 k for six and 165 k for eight): the other waves of
-// the SIMD cover the key latency, the registers of a deeper ring are not free -- with three, k_ksx_main spills nothing.
+// the SIMD cover the key latency, the registers of a deeper ring are not free -- with three, k_ksx_main spills nothing INSIDE its
+// round loop (compiler, round 4: 5 VGPRs / 16 bytes of scratch per lane in all, one dword reloaded at the top of every round and
+// the rest between the two mod-down rounds: hipcc -Rpass-analysis=kernel-resource-usage, tools/kres.sh).
 #ifndef KX_PF_DEPTH
 #define KX_PF_DEPTH 3
 #endif
