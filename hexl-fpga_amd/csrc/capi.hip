@@ -422,8 +422,9 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 static unsigned host_threads() {                                   // (thread-safe static: several device runners call this)
     static const unsigned n = [] {
         const char* e = getenv("HEXL_HOST_THREADS");
-        // 8: swept on the 256-thread boxes of this pool (tools/r3_run_k.sh): 2 / 4 / 8 / 12 / 32 / 64 copy threads move 12 / 21 / 26 / 27 /
+        // 8: swept on the 256-thread boxes of this pool (round 3, HEXL_HOST_THREADS sweep of tests/cpp/bench_cxx_api): 2 / 4 / 8 / 12 / 32 / 64 copy threads move 12 / 21 / 26 / 27 /
         // 19 / 12 k keyswitch/s through the host-pointer API at worksize 1024 -- the copies are memory-bound, more threads only contend
+        // (round 4: those pods run under a CFS quota of 16 cores, bench.py cpu_baseline.cgroup_cpu_quota_cores -- a host without one may want more)
         const unsigned v = e ? (unsigned)atoi(e) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
         return v ? v : 1u;
     }();
