@@ -77,6 +77,23 @@ __device__ __attribute__((noinline)) void slow_inv(u64* px, u64* lds, const u64*
 // or colliding hint can only cost speed -- still runs the prepare kernel, and clears the hint once the tables verify.
 struct NttHint { unsigned long long* word; unsigned long long tag; };
 
+// Round 4: what the FP64 fast path takes. The lazy kernels (q <= 2^51 (1 + 2^-7)) take words below min(1.25 q, 2^52) AS THEY ARE --
+// the two-instruction conversion, no range reduction -- on the reduction schedule shifted by one stage (f64_arith.hpp
+// lazy_fwd_reduce_after; the inverse's first stage only needs X + Y < 2.5 q and |X - Y| < 1.25 q): 64 of ~1500 VALU instructions per
+// polynomial. Canonical inputs -- the case that matters -- are below q; words in [1.25 q, 4 q) (forward) / [1.25 q, 2 q) (inverse) are
+// inside the Harvey contract, so those polynomials now go to the integer butterflies like out-of-contract ones (same answer, slower).
+// The strict kernels (q up to 2^52) keep the full Harvey range and centre their inputs.
+template <int LAZY>
+__device__ __forceinline__ u64 fast_path_limit(u64 q, bool forward) {
+    if constexpr (LAZY != 0) { const u64 l = q + (q >> 2); return l < (1ull << 52) ? l : (1ull << 52); }
+    else return forward ? ((q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53)) : (q << 1);
+}
+template <int LAZY>
+__device__ __forceinline__ double fast_path_input(u64 raw, const Mod m) {
+    if constexpr (LAZY != 0) return hxf::to_f64_lt52(raw);
+    else return hxf::reduce(hxf::to_f64(raw), m);
+}
+
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restrict__ x, const u64* __restrict__ roots,
                                                                   const u64* __restrict__ precon, u64 q,
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
         slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
         return;
     }
-    const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
+    const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
     double f[G::E];
@@ -104,12 +121,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     for (int r = 0; r < G::E; ++r) {
         const u64 raw = px[G::idxA(r, tid)];
         out_of_range |= raw >= limit;
-        f[r] = hxf::reduce(hxf::to_f64(raw), m);
+        f[r] = fast_path_input<LAZY>(raw, m);
     }
     // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
-    WgNttF64<LOGN, LOGE, LAZY>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
 #pragma unroll
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
         slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
         return;
     }
-    const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
+    const u64 limit = fast_path_limit<LAZY>(q, false);
     const Mod m{(double)q, 1.0 / (double)q};
     bool out_of_range = false;
     double f[G::E];
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
     for (int r = 0; r < G::E; ++r) {
         const u64 raw = px[G::idxB(r, tid)];
         out_of_range |= raw >= limit;
-        f[r] = hxf::reduce(hxf::to_f64(raw), m);
+        f[r] = fast_path_input<LAZY>(raw, m);
     }
     WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
     const bool slow = __syncthreads_or(out_of_range);                            // see k_ntt_fwd_x
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
                                                                   const u32* __restrict__ violations, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const u64 limit = (q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53);      // Harvey input range, exactly convertible
+    const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
     if (*violations != 0) {
         // Tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones): known at kernel entry,
@@ -232,14 +249,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
 #pragma unroll
         for (int r = 0; r < G::E; ++r) {
             out_of_range |= raw[r] >= limit;
-            f[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
+            f[r] = fast_path_input<LAZY>(raw[r], m);
         }
         vote.cast(out_of_range);
         const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;                // (last round: a harmless re-read)
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
 #pragma unroll
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
                                                                   const u32* __restrict__ violations, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const u64 limit = q << 1;                                                   // < 2^53 since q < 2^52
+    const u64 limit = fast_path_limit<LAZY>(q, false);
     const Mod m{(double)q, 1.0 / (double)q};
     if (*violations != 0) {                                                     // see k_ntt_fwd_p
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 #pragma unroll
         for (int r = 0; r < G::E; ++r) {
             out_of_range |= raw[r] >= limit;
-            f[r] = hxf::reduce(hxf::to_f64(raw[r]), m);
+            f[r] = fast_path_input<LAZY>(raw[r], m);
         }
         vote.cast(out_of_range);
         // the inverse starts with its per-lane twiddle pass: the next input is requested behind that pass's twiddles,

@@ -294,7 +294,7 @@ static void test_round4(uint64_t n, uint64_t p, int period, double rho, bool adv
 }
 
 // inverse without the w/p table, canonical input words as they are; lazy = the lazy kernels' schedule, else the strict one
-static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversarial) {
+static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversarial, double rho = 1.0) {
     hxf::Mod m{(double)p, 1.0 / (double)p};
     std::vector<uint64_t> blk(4 * n);
     orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
@@ -303,7 +303,13 @@ static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversaria
     std::vector<uint64_t> x(n), ref;
     orc_fill_splitmix(x.data(), n, p ^ (n + 99), p);
     if (adversarial) for (uint64_t i = 0; i < n; ++i) x[i] = (i & 1) ? p - 1 : ((i & 2) ? 0 : p - 2);
-    ref = x; orc_ks_intt(ref.data(), n, p, inv0);
+    if (rho > 1.0) {                                                   // words of the standalone inverse's fast path: below rho p, as they are
+        const uint64_t top = (uint64_t)(rho * (double)p) - 1;
+        for (uint64_t i = 0; i < n; ++i) x[i] = adversarial ? ((i & 1) ? top : ((i & 2) ? 0 : top - 1)) : rnd() % (top + 1);
+    }
+    ref = x;
+    for (auto& v : ref) v %= p;
+    orc_ks_intt(ref.data(), n, p, inv0);
     std::vector<double> v(n);
     for (uint64_t i = 0; i < n; ++i) v[i] = hxf::to_f64_lt52(x[i]);
     const double ninv = centre(orc_invmod(n, p)), ninv_p = ninv / (double)p;
@@ -365,6 +371,7 @@ int main() {
                 for (int adv = 0; adv < 2; ++adv) {
                     if ((double)p > (double)(1ull << 50)) { test_round4(n, p, 3, hxf::LAZY_SKIP_MAX_RATIO, adv); test_round4(n, p, 3, 1.008, adv); }
                     test_inverse_nowp(n, p, true, adv);
+                    test_inverse_nowp(n, p, true, adv, hxf::LAZY_SKIP_MAX_RATIO);       // standalone _INTT fast path (ntt.hip fast_path_limit)
                 }
         std::printf("lazy schedules: max |x| seen = 2^%.3f (limit 2^53)\n", log2(g_max_abs));
         CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded");
