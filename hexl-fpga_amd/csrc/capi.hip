@@ -273,7 +273,7 @@ extern "C" int hexl_ks_plan_destroy(hexl_ks_plan* p) {
     if (p->d_tables) (void)hipFree(p->d_tables);
     if (p->d_keys) (void)hipFree(p->d_keys);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < HX_KS_MAX_LANES; ++l) {
         if (p->aux[l]) (void)hipStreamDestroy(p->aux[l]);
         if (p->ev_done[l]) (void)hipEventDestroy(p->ev_done[l]);
     }

@@ -88,6 +88,11 @@ struct KsModF64 {
     double half;         // floor(q_sp/2)
 };
 
+// lanes (auxiliary streams) the chunks of one keyswitch call alternate between: 2 in production; HEXL_KS_LANES=3|4 is the
+// experiment that bounds what a single launch per chunk could gain (tools/experiments/README.md, round 4)
+constexpr int HX_KS_MAX_LANES = 4;
+int hx_ks_lanes();
+
 struct hexl_ks_plan {
     hexl_ctx* ctx = nullptr;
     u32 n = 0, logn = 0, L = 0, K = 0, rns = 0;
@@ -109,10 +114,10 @@ struct hexl_ks_plan {
     // scratch for `cap` keyswitches per lane; two lanes (aux streams) work on alternating chunks so that kernels
     // of different kinds -- FP64-bound transforms and the HBM-bound multiply-accumulate -- share the chip and one
     // chunk's ragged last wave of workgroups is filled by the other's
-    u64* d_scratch = nullptr;         // [2 lanes][cap * scratch_words * n]
+    u64* d_scratch = nullptr;         // [lanes][cap * scratch_words * n]
     size_t cap = 0;
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
+    hipStream_t aux[HX_KS_MAX_LANES] = {};
+    hipEvent_t ev_start = nullptr, ev_done[HX_KS_MAX_LANES] = {};
     u32* d_flag = nullptr;            // one device word + its pinned host mirror: input-range flag (HEXL_KS_VALIDATE)
     u32* h_flag = nullptr;
     double* d_keys_nat = nullptr;     // N = 16384 FP64 plans: the keys as centred doubles in NATURAL order (latency path, keyswitch_lat.hip)

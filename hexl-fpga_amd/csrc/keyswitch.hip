@@ -428,9 +428,13 @@ size_t hx_ks_f64_scratch_words(size_t L);
 static size_t scratch_words(const hexl_ks_plan* p) {           // per instance, in units of n 64-bit words
     return p->use_f64 ? hx_ks_f64_scratch_words(p->L) : size_t(3) * p->L + 2;
 }
+int hx_ks_lanes() {
+    static const int v = [] { const char* e = getenv("HEXL_KS_LANES"); const int l = e ? atoi(e) : 2; return l < 2 ? 2 : l > HX_KS_MAX_LANES ? HX_KS_MAX_LANES : l; }();
+    return v;
+}
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* p, size_t batch) {
     const size_t chunk = batch < ks_chunk_default(p) ? batch : ks_chunk_default(p);
-    return 2 * chunk * scratch_words(p) * p->n * sizeof(u64);      // two lanes
+    return size_t(hx_ks_lanes()) * chunk * scratch_words(p) * p->n * sizeof(u64);      // two lanes
 }
 
 // HEXL_KS_VALIDATE=1: the keyswitch precondition (every t_target / result word below its modulus), checked on the device
@@ -493,31 +497,31 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
     if (p->cap < chunk) {
         if (p->d_scratch) { HX_CHECK(hipDeviceSynchronize()); HX_CHECK(hipFree(p->d_scratch)); }
         p->d_scratch = nullptr; p->cap = 0;
-        HX_CHECK(hipMalloc((void**)&p->d_scratch, 2 * lane_words * sizeof(u64)));
+        HX_CHECK(hipMalloc((void**)&p->d_scratch, size_t(hx_ks_lanes()) * lane_words * sizeof(u64)));
         p->cap = chunk;
     }
     if (!p->aux[0]) {
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < hx_ks_lanes(); ++l) {
             HX_CHECK(hipStreamCreateWithFlags(&p->aux[l], hipStreamNonBlocking));
             HX_CHECK(hipEventCreateWithFlags(&p->ev_done[l], hipEventDisableTiming));
         }
         HX_CHECK(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
     }
     hipStream_t user = p->ctx->stream;
-    const int lanes = two_lanes ? 2 : 1;
-    if (lanes == 2) {                                                 // lanes start after everything queued so far
+    const int lanes = two_lanes ? hx_ks_lanes() : 1;
+    if (lanes >= 2) {                                                 // lanes start after everything queued so far
         HX_CHECK(hipEventRecord(p->ev_start, user));
         for (int l = 0; l < lanes; ++l) HX_CHECK(hipStreamWaitEvent(p->aux[l], p->ev_start, 0));
     }
     const size_t n = p->n, L = p->L;
-    // lane 1's first chunk is half-sized: the lanes then run out of phase, so one lane's HBM-bound kernels overlap
+    // lane 1's first chunk is half-sized (lane l's: l / lanes): the lanes then run out of phase, so one lane's HBM-bound kernels overlap
     // the other's FP64-bound ones instead of both running the same kernel side by side
     size_t ci = 0, nb = 0;
     for (size_t b0 = 0; b0 < batch; b0 += nb, ++ci) {
-        const size_t want = (lanes == 2 && ci == 1 && !p->use_f64) ? (chunk + 1) / 2 : chunk;
+        const size_t want = (lanes >= 2 && ci >= 1 && ci < (size_t)lanes && !p->use_f64) ? (chunk * ci + lanes - 1) / lanes : chunk;
         nb = (batch - b0 < want) ? batch - b0 : want;
         const int lane = (int)(ci % lanes);
-        p->cur = lanes == 2 ? p->aux[lane] : user;                   // one lane: straight on the caller's stream
+        p->cur = lanes >= 2 ? p->aux[lane] : user;                   // one lane: straight on the caller's stream
         p->cur_scratch = p->d_scratch + size_t(lane) * p->cap * scratch_words(p) * n;
         int rc;
         if (p->use_f64 && hx_ks_x_applies(p, nb)) {
@@ -555,7 +559,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, s
         }
         if (rc) return rc;
     }
-    for (int l = 0; lanes == 2 && l < lanes; ++l) {                    // the caller's stream continues after both lanes
+    for (int l = 0; lanes >= 2 && l < lanes; ++l) {                    // the caller's stream continues after both lanes
         HX_CHECK(hipEventRecord(p->ev_done[l], p->aux[l]));
         HX_CHECK(hipStreamWaitEvent(user, p->ev_done[l], 0));
     }
@@ -574,7 +578,7 @@ int hx_launch_multiply_relinearize(hexl_ks_plan* p, u64* d_out, const u64* d_a, 
     if (p->cap < chunk) {
         if (p->d_scratch) { HX_CHECK(hipDeviceSynchronize()); HX_CHECK(hipFree(p->d_scratch)); }
         p->d_scratch = nullptr; p->cap = 0;
-        HX_CHECK(hipMalloc((void**)&p->d_scratch, 2 * lane_words * sizeof(u64)));
+        HX_CHECK(hipMalloc((void**)&p->d_scratch, size_t(hx_ks_lanes()) * lane_words * sizeof(u64)));
         p->cap = chunk;
     }
     p->cur = p->ctx->stream;
