@@ -40,6 +40,14 @@
 //    quotients from the products (no w/p table: half the per-lane twiddle bytes). 5.7 % fewer VALU instructions per keyswitch.
 #include <stdlib.h>
 
+// Wave priority by pass of the forward transforms (ntt_core_f64.hpp hx_fwd_prio; round 4): the pass in front of the cross-wave
+// barrier runs at priority 0, everything behind it at 1. The four waves of a SIMD are staggered by up to a barrier interval (the
+// oldest wave wins every issue slot, tools/ksx_timeline gantt): a wave that is a round ahead only reaches the barrier to wait there,
+// while the wave it waits for is still finishing the previous round's passes and multiply-accumulate on the same SIMD -- the leader's
+// first pass should fill the laggard's stalls, not compete with it. +2.4 ... 2.9 % on three boxes (tools/experiments/README.md).
+#ifndef HX_FWD_PRIO
+#define HX_FWD_PRIO 1222
+#endif
 #include "hexl_internal.hpp"
 #include "ntt_core_f64.hpp"
 
@@ -69,6 +77,9 @@ using namespace hx;
 #endif
 #ifndef KX_PRIO_MASK
 #define KX_PRIO_MASK 0  // k_ksx_main: waves whose number has a bit of this mask set run at s_setprio 1 (experiment)
+#endif
+#ifndef KX_MAC_PRIO
+#define KX_MAC_PRIO 0   // wave priority + 1 of the multiply-accumulate phase (0 = inherit the transform's last pass; HX_FWD_PRIO)
 #endif
 #ifndef KX_KEY_AUX
 #define KX_KEY_AUX 0    // ... of the key loads
@@ -115,7 +126,7 @@ constexpr int KX_NST = 64;
     do {                                                                                                       \
         _Pragma("unroll") for (int r_ = 0; r_ < G::E; ++r_) asm volatile("" : "+v"(v[r_]));                    \
         if (a.stamps && (threadIdx.x & 63) == 0)                                                               \
-            a.stamps[(size_t(blockIdx.x) * (G::T / 64) + (threadIdx.x >> 6)) * KX_NST + (i)] = __builtin_readcyclecounter(); \
+            a.stamps[(size_t(kx_slot) * (G::T / 64) + (threadIdx.x >> 6)) * KX_NST + (i)] = __builtin_readcyclecounter(); \
         _Pragma("unroll") for (int r_ = 0; r_ < G::E; ++r_) asm volatile("" : "+v"(v[r_]));                    \
     } while (0)
 #else
@@ -133,6 +144,17 @@ __device__ __forceinline__ XcdWalk xcd_walk(u32 total) {
     const u32 g = gridDim.x >> 3, q = total >> 3, r = total & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const u32 start = x * q + (x < r ? x : r);
     return XcdWalk{start + j, start + q + (x < r ? 1u : 0u), g};
+}
+
+// the per-modulus constants of limb i, read through the constant address space (ten doubles: scalar loads)
+__device__ __forceinline__ KsModF64 load_mod_const(const KsModF64* p) {
+    static_assert(sizeof(KsModF64) == 10 * sizeof(double), "KsModF64 is ten doubles");
+    const ctw_t q = (ctw_t)(const double*)p;
+    KsModF64 f;
+    f.m.p = q[0]; f.m.pinv = q[1];
+    f.sc.n = q[2]; f.sc.n_p = q[3]; f.sc.nw = q[4]; f.sc.nw_p = q[5];
+    f.msf = q[6]; f.msf_p = q[7]; f.fix = q[8]; f.half = q[9];
+    return f;
 }
 
 // key[d][slot][0] (key[d][slot][1] follows it, n words further)
@@ -195,6 +217,9 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
                                          const double* __restrict__ k0, const double* __restrict__ next, int tid,
                                          const Mod m) {
     constexpr int PF = KX_PF;
+#if KX_MAC_PRIO
+    __builtin_amdgcn_s_setprio(KX_MAC_PRIO - 1);
+#endif
     const RowStream<double> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8;
     double ka[PF], kb[PF];
@@ -376,6 +401,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     for (u32 b = wk.pos; b < wk.end; b += wk.step) {
     double acc0[G::E], acc1[G::E];
     double v[G::E];                                               // between rounds: the next round's input, A order
+#ifdef KX_TIMELINE
+    const u32 kx_slot = b;
+#endif
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -570,11 +598,18 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
 #if KX_MAIN_PERSIST
     const XcdWalk wk = xcd_walk(a.nb * L);
 #pragma unroll 1
-    for (u32 item = wk.pos; item < wk.end; item += wk.step)
+    for (u32 item_v = wk.pos; item_v < wk.end; item_v += wk.step)
 #else
-    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));
+    const u32 item_v = xcd_item_x(blockIdx.x, gridDim.x);
 #endif
     {
+    const u32 item = __builtin_amdgcn_readfirstlane(item_v);
+#if KX_MAIN_PERSIST && HX_FWD_PRIO
+    __builtin_amdgcn_s_setprio(HX_FWD_PRIO / 1000 - 1);          // the d == i phase of the next item: as low as a first pass
+#endif
+#ifdef KX_TIMELINE
+    const u32 kx_slot = item;
+#endif
 #if KX_SLOT_MAJOR
     // SLOT-major, XCD-contiguous: an XCD works on one or two limbs at a time, whose keys (2 L n words per limb) then
     // stay in its L2; c_d and s' of one instance are fetched by up to L XCDs (the Infinity Cache absorbs that)
@@ -583,7 +618,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     // instance-major, XCD-contiguous: the L workgroups that read the same c_d and s' run side by side on one XCD
     const u32 b = item / L, i = item - b * L;
 #endif
-    const KsModF64 md = a.mods[i];
+    // (through the constant address space: inside an item loop that also stores to global memory a plain read of these
+    // wave-uniform constants becomes a VECTOR load, and p, 1/p, msf ... then occupy vector registers the accumulators need)
+    const KsModF64 md = load_mod_const(a.mods + i);
     const Mod m = md.m;
     // round `it` reads c_it (it < L, skipping it == i) or s'_{it-L}
     const u32 bc = KX_ALIASED(2, b), bt = KX_ALIASED(4, b), br = KX_ALIASED(8, b);

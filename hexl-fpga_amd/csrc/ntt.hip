@@ -5,6 +5,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+// wave priority by pass of the FP64 forward transforms: the pass in front of the cross-wave barrier at 0, the rest at 1
+// (keyswitch_x.hip has the reasoning; standalone forward NTT +5 % at batch 1024, +3.5 % at batch 4096; the inverse transforms'
+// knob HX_INV_PRIO measured within +-2 % either way and stays off)
+#ifndef HX_FWD_PRIO
+#define HX_FWD_PRIO 1222
+#endif
 #include "hexl_internal.hpp"
 #include "ntt_core.hpp"
 #include "ntt_core_f64.hpp"

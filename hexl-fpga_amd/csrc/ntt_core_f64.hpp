@@ -225,6 +225,30 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
 // (194 k -> 200 k keyswitch/s); PRE >= 10: the per-lane full pass requests its early stages' twiddles up front as well
 // (fwd_stages_f64_ahead: -> 202 k). Left alone, a kernel that holds 96 data registers gets every twiddle load of that pass right in
 // front of its first use with an s_waitcnt vmcnt(0) behind it -- eight fully exposed L2 latencies per transform.
+// Experiment knob: wave priority by pass of a forward transform. HX_FWD_PRIO = four decimal digits d0 d1 d2 d3, pass k runs at
+// s_setprio(dk - 1) (0 = knob off); whatever follows the transform inherits the last pass's priority.
+#ifndef HX_FWD_PRIO
+#define HX_FWD_PRIO 0
+#endif
+template <int PASS>
+__device__ __forceinline__ void hx_fwd_prio() {
+    if constexpr (HX_FWD_PRIO != 0 && PASS < 4) {
+        constexpr int d = PASS == 0 ? HX_FWD_PRIO / 1000 : PASS == 1 ? (HX_FWD_PRIO / 100) % 10 : PASS == 2 ? (HX_FWD_PRIO / 10) % 10 : HX_FWD_PRIO % 10;
+        __builtin_amdgcn_s_setprio(d - 1);
+    }
+}
+// ... and of an inverse transform: HX_INV_PRIO digits = partial first pass, the two wave-private passes, the pass behind the
+// cross-wave re-deal (the geometry of N = 16384: four passes)
+#ifndef HX_INV_PRIO
+#define HX_INV_PRIO 0
+#endif
+template <int PH>
+__device__ __forceinline__ void hx_inv_prio() {
+    if constexpr (HX_INV_PRIO != 0 && PH < 4) {
+        constexpr int d = PH == 0 ? HX_INV_PRIO / 1000 : PH == 1 ? (HX_INV_PRIO / 100) % 10 : PH == 2 ? (HX_INV_PRIO / 10) % 10 : HX_INV_PRIO % 10;
+        __builtin_amdgcn_s_setprio(d - 1);
+    }
+}
 #ifndef HX_KEEP_LAST_REDUCE
 #define HX_KEEP_LAST_REDUCE 0   // 1: A/B variant that keeps the periodic reduction on the last stage of the shifted schedule
 #endif
@@ -248,6 +272,7 @@ struct WgNttF64 {
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
                                                     const double* wp, const Mod m, Hook after_cross = Hook(),
                                                     Hook2 before_last = Hook2()) {
+        hx_fwd_prio<PASS>();
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
@@ -355,6 +380,7 @@ struct WgNttF64 {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
             constexpr bool LEAD = !(FRESH && PASS == 0);
+            hx_inv_prio<PASS + 1>();
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             if constexpr (inv_pass_uniform<PASS> && (PASS == 0 || !inv_pass_uniform<(PASS > 0 ? PASS - 1 : 0)>)) before_uniform();
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
@@ -367,6 +393,7 @@ struct WgNttF64 {
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
                                                    const double* iwp, const Mod m, const InvScale sc,
                                                    Hook before_uniform = Hook()) {
+        hx_inv_prio<0>();
         inv_first<0, IPRE>(v, tid, iw, iwp, m, sc);
         inv_pass<0, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform);
     }

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             hipMemset(dst, 0, nst * 8);
             hipEventRecord(e0);
-            if (which) hipLaunchKernelGGL(kmn, dim3(grid), dim3(G::T), G::LDS_USED, 0, a);
+            if (which) hipLaunchKernelGGL(kmn, dim3(KX_MAIN_PERSIST ? 256u : grid), dim3(G::T), G::LDS_USED, 0, a);
             else       hipLaunchKernelGGL(ksp, dim3(grid), dim3(G::T), G::LDS_USED, 0, a);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
@@ -110,6 +110,22 @@ int main(int argc, char** argv) {
                 t0 = std::min(t0, start); t1 = std::max(t1, ev.back().second); emin = std::min(emin, ev.back().second);
             }
             span += double(t1 - t0); skew += double(t1 - emin);
+        }
+        if (argc > 3) {   // per-wave Gantt of ONE workgroup (argv[3]): stamps relative to the workgroup's first, in cycles
+            const u32 g = (u32)atoi(argv[3]) % grid;
+            unsigned long long base = ~0ull;
+            for (int w = 0; w < W; ++w) for (int i = 0; i < KX_NST; ++i) { const unsigned long long x = s[(size_t(g) * W + w) * KX_NST + i]; if (x && x < base) base = x; }
+            printf("  gantt of item %u, first stamp at absolute cycle %llu (columns: stamp index; rows: wave, SIMD = wave %% 4)\n        ", g, base);
+            std::vector<int> cols;
+            if (which) { cols.push_back(60); cols.push_back(61); }
+            for (int i = 0; i <= endi; ++i) { bool any = false; for (int w = 0; w < W; ++w) any |= s[(size_t(g) * W + w) * KX_NST + i] != 0; if (any) cols.push_back(i); }
+            for (int c : cols) printf("%8d", c);
+            printf("\n");
+            for (int w = 0; w < W; ++w) {
+                printf("  w%02d s%d ", w, w % 4);
+                for (int c : cols) printf("%8lld", (long long)(s[(size_t(g) * W + w) * KX_NST + c] - base));
+                printf("\n");
+            }
         }
         if (which) printf("  diagonal: load t_i -> B %8.0f cycles, multiply-accumulate (+ first input request) %8.0f cycles\n", diag_ld / nd, diag_mac / nd);
         const char* nm_sp[4] = {"wait for input + reduce | inverse + store s' (last two)", "forward transform", "multiply-accumulate", ""};
