@@ -11,6 +11,12 @@
 #include <stdlib.h>
 
 #include "hexl_internal.hpp"
+#ifndef KSF_BIG_PRIO
+#define KSF_BIG_PRIO 1222  // ... in k_ksf_ntt_up / k_ksf_moddown at N = 32768 (32 coefficients per thread, half-size re-deals)
+#endif
+#ifndef KSF_UP_PRIO
+#define KSF_UP_PRIO 1222   // wave priority by pass in k_ksf_up (0 = off)
+#endif
 #include "ntt_core_f64.hpp"
 
 using namespace hx;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (batch 32 at N = 16384: -5 %)
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -111,7 +117,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    // FPRIO 1222: this workgroup runs L transforms back to back -- the pass in front of the cross-wave barrier at the lower wave
+    // priority (ntt_core_f64.hpp hx_fwd_prio): N = 32768, L = 3, batch 2048: 143.5 k -> 163.5 k keyswitch/s (+14 %)
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, false, KSF_UP_PRIO>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const u32 L = a.L;
     const u32 item = blockIdx.x;                                  // b*L + d
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (N = 16384: +-0)
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;

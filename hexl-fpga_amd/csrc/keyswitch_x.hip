@@ -81,6 +81,12 @@ using namespace hx;
 #ifndef KX_MAC_PRIO
 #define KX_MAC_PRIO 0   // wave priority + 1 of the multiply-accumulate phase (0 = inherit the transform's last pass; HX_FWD_PRIO)
 #endif
+#ifndef KX_EPI_PRIO
+#define KX_EPI_PRIO 0   // ... of the mod-down epilogue (result read-modify-write)
+#endif
+#ifndef KX_MACEND_PRIO
+#define KX_MACEND_PRIO 0   // ... from the end of a multiply-accumulate (the wait for the next round's input)
+#endif
 #ifndef KX_KEY_AUX
 #define KX_KEY_AUX 0    // ... of the key loads
 #endif
@@ -240,6 +246,9 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#if KX_MACEND_PRIO
+    __builtin_amdgcn_s_setprio(KX_MACEND_PRIO - 1);
+#endif
 }
 
 // The FIRST multiply-accumulate of a workgroup (the d == i term): the accumulators are not live yet, so all 2 E key words
@@ -496,6 +505,9 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     } else {
         W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);           // |w| <= 2.14p
     }
+#if KX_EPI_PRIO
+    __builtin_amdgcn_s_setprio(KX_EPI_PRIO - 1);
+#endif
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
     if constexpr (NPF > 0) {

@@ -11,6 +11,12 @@
 #ifndef HX_FWD_PRIO
 #define HX_FWD_PRIO 1222
 #endif
+// ... and of the INTEGER inverse transforms (persistent k_ntt_inv_ip: moduli >= 2^52, tables that are not Shoup tables): the
+// pass in front of the cross-wave barrier at 0, the others at 1: 8.9 M -> 9.7 M inverse NTT/s at q = 2^52 + 393217, batch 1024
+// (1112: 9.1 M; the integer forward kernel runs one transform per workgroup and does not react to its knob)
+#ifndef HX_IINV_PRIO
+#define HX_IINV_PRIO 2212
+#endif
 #include "hexl_internal.hpp"
 #include "ntt_core.hpp"
 #include "ntt_core_f64.hpp"

@@ -15,6 +15,13 @@
 //   * twiddles come from the caller's tables (bit-reversed order) through L2; the first
 //     pass's indices are uniform so the compiler emits scalar loads for them.
 #pragma once
+#ifndef HX_IFWD_PRIO
+#define HX_IFWD_PRIO 0   // four digits, pass k of an integer forward transform at s_setprio(digit - 1); 0 = off (WgNtt::prio)
+#endif
+#ifndef HX_IINV_PRIO
+#define HX_IINV_PRIO 0   // ... of an integer inverse transform
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -392,11 +399,20 @@ struct WgNtt {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
 
+    // experiment knobs, as HX_FWD_PRIO / HX_INV_PRIO of ntt_core_f64.hpp: wave priority by pass of the INTEGER transforms
+    template <int KNOB, int PH>
+    __device__ static __forceinline__ void prio() {
+        if constexpr (KNOB != 0 && PH < 4) {
+            constexpr int d = PH == 0 ? KNOB / 1000 : PH == 1 ? (KNOB / 100) % 10 : PH == 2 ? (KNOB / 10) % 10 : KNOB % 10;
+            __builtin_amdgcn_s_setprio(d - 1);
+        }
+    }
     // ---- forward: v in A layout on entry, B layout on exit; values in [0,4q) (lazy) ---------
     // FRESH: no other LDS traffic of this workgroup can still be in flight (single-transform kernels)
     template <int PASS, bool FRESH = false>
     __device__ static __forceinline__ void fwd_pass(u64 (&v)[E], u64* lds, int tid,
                                                     const u64* roots, const u64* precon, u64 q, u64 twoq) {
+        prio<HX_IFWD_PRIO, PASS>();
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // pass 0 has no index bits above its field: constant twiddle addresses -> scalar loads
@@ -453,6 +469,7 @@ struct WgNtt {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
             constexpr bool LEAD = !(FRESH && PASS == 0);
+            prio<HX_IINV_PRIO, PASS + 1>();
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iroots, iprecon, q, twoq, a, ap, b, bp);
@@ -464,6 +481,7 @@ struct WgNtt {
                                                    const u64* iprecon, u64 q, u64 inv_n, u64 inv_n_p,
                                                    u64 inv_n_w, u64 inv_n_w_p) {
         const u64 twoq = q << 1;
+        prio<HX_IINV_PRIO, 0>();
         inv_first<0>(v, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
         inv_pass<0, FRESH>(v, lds, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
     }

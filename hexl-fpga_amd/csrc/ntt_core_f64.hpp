@@ -225,15 +225,18 @@ __device__ __forceinline__ void redeal_f64(double (&v)[G::E], double* lds, int t
 // (194 k -> 200 k keyswitch/s); PRE >= 10: the per-lane full pass requests its early stages' twiddles up front as well
 // (fwd_stages_f64_ahead: -> 202 k). Left alone, a kernel that holds 96 data registers gets every twiddle load of that pass right in
 // front of its first use with an s_waitcnt vmcnt(0) behind it -- eight fully exposed L2 latencies per transform.
-// Experiment knob: wave priority by pass of a forward transform. HX_FWD_PRIO = four decimal digits d0 d1 d2 d3, pass k runs at
-// s_setprio(dk - 1) (0 = knob off); whatever follows the transform inherits the last pass's priority.
+// Wave priority by pass of a forward transform: four decimal digits d0 d1 d2 d3, pass k runs at s_setprio(dk - 1) (0 = off);
+// whatever follows the transform inherits the last pass's priority. HX_FWD_PRIO is the translation unit's default for WgNttF64's
+// FPRIO parameter. 1222 -- the pass in front of the cross-wave barrier below everything else -- pays in kernels whose workgroups
+// run transform after transform (keyswitch_x.hip has the reasoning and the numbers); a workgroup that runs ONE transform loses a
+// few per cent with it (k_ksf_ntt_up / k_ksf_moddown at batch 32: -4 %), so it is chosen per kernel.
 #ifndef HX_FWD_PRIO
 #define HX_FWD_PRIO 0
 #endif
-template <int PASS>
+template <int PASS, int KNOB = HX_FWD_PRIO>
 __device__ __forceinline__ void hx_fwd_prio() {
-    if constexpr (HX_FWD_PRIO != 0 && PASS < 4) {
-        constexpr int d = PASS == 0 ? HX_FWD_PRIO / 1000 : PASS == 1 ? (HX_FWD_PRIO / 100) % 10 : PASS == 2 ? (HX_FWD_PRIO / 10) % 10 : HX_FWD_PRIO % 10;
+    if constexpr (KNOB != 0 && PASS < 4) {
+        constexpr int d = PASS == 0 ? KNOB / 1000 : PASS == 1 ? (KNOB / 100) % 10 : PASS == 2 ? (KNOB / 10) % 10 : KNOB % 10;
         __builtin_amdgcn_s_setprio(d - 1);
     }
 }
@@ -254,7 +257,7 @@ __device__ __forceinline__ void hx_inv_prio() {
 #endif
 // FSHIFT: phase of the forward reduction schedule (1: un-centred inputs, f64_arith.hpp); NOWP: inverse transforms without
 // the w/p table
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false>
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO>
 struct WgNttF64 {
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -272,7 +275,7 @@ struct WgNttF64 {
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
                                                     const double* wp, const Mod m, Hook after_cross = Hook(),
                                                     Hook2 before_last = Hook2()) {
-        hx_fwd_prio<PASS>();
+        hx_fwd_prio<PASS, FPRIO>();
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
