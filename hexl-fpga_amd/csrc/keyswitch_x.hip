@@ -65,6 +65,17 @@ using namespace hx;
 #ifndef KX_FIRST_DIRECT
 #define KX_FIRST_DIRECT 1   // first multiply-accumulate of k_ksx_main with its keys requested straight into the accumulators
 #endif
+#ifndef KX_DL_SELECT
+#define KX_DL_SELECT 0   // DL: 1 = one loop over all d != i with a run-time choice of the next-input addressing in its multiply-accumulate
+#endif
+#ifndef KX_DL_PF
+#define KX_DL_PF 2       // key ring depth of the two peeled multiply-accumulates of k_ksx_main<..., DL>
+#endif
+#ifndef KX_DIAG_LATE
+#define KX_DIAG_LATE 0   // 1: k_ksx_main<..., DL> (the d == i term as the LAST multiply-accumulate of the mod-up instead of a start-up phase of
+                         // its own) is built and used for N = 16384, L >= 2 (HEXL_KSX_DIAG=0 switches back at run time). Bit-exact; measured
+                         // 203.5 k against 214.6 k keyswitch/s: the two peeled multiply-accumulates spill accumulators (tools/experiments)
+#endif
 #ifndef KX_PRE
 #define KX_PRE 11     // forward transforms: twiddles of the per-lane passes requested early (ntt_core_f64.hpp WgNttF64 PRE): units = groups of
                       // the last pass ahead of its re-deal, tens = early stages of the per-lane full pass up front
@@ -218,16 +229,20 @@ constexpr int KX_PF = KX_PF_DEPTH;
 #ifndef KX_FOLD
 #define KX_FOLD 1     // lazy kernels: folded multiply-accumulate (f64_arith.hpp mac_fold), accumulators <= 1.6p between rounds
 #endif
-template <class G, bool FOLD = false>
+// NEXTB: the next input is read at the B-order positions of a natural-order array (the raw t_i words of the d == i term,
+// k_ksx_main<..., DL>) instead of the usual A-order rows.
+template <class G, bool FOLD = false, int NEXTB = 0, int PF = KX_PF>
 __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
                                          const double* __restrict__ k0, const double* __restrict__ next, int tid,
-                                         const Mod m) {
-    constexpr int PF = KX_PF;
+                                         const Mod m, bool next_at_B = false) {
 #if KX_MAC_PRIO
     __builtin_amdgcn_s_setprio(KX_MAC_PRIO - 1);
 #endif
     const RowStream<double> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8;
+    const bool nb = NEXTB == 1 || (NEXTB == 2 && next_at_B);        // (2: wave-uniform, chosen per call: sixteen scalar selects)
+    const u32 ntoff = nb ? u32(G::idxB(0, tid)) * 8 : toff;
+    auto next_row = [&](int r) -> u32 { return nb ? u32(G::idxB(r, 0)) * 8 : u32(G::idxA(r, 0)) * 8; };
     double ka[PF], kb[PF];
 #pragma unroll
     for (int r = 0; r < PF; ++r) { ka[r] = keys.template at<KX_KEY_AUX>(toff, r * G::T * 8); kb[r] = keys.template at<KX_KEY_AUX>(toff, (G::N + r * G::T) * 8); }
@@ -236,7 +251,7 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
         const double a = ka[r % PF], b = kb[r % PF];
         if (r + PF < G::E) { ka[r % PF] = keys.template at<KX_KEY_AUX>(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.template at<KX_KEY_AUX>(toff, (G::N + (r + PF) * G::T) * 8); }
         const double x = v[r];
-        v[r] = nxt.template at<KX_NEXT_AUX>(toff, G::idxA(r, 0) * 8);
+        v[r] = nxt.template at<KX_NEXT_AUX>(ntoff, next_row(r));
         if constexpr (FOLD) {
             acc0[r] = hxf::mac_fold(acc0[r], x, a, m);
             acc1[r] = hxf::mac_fold(acc1[r], x, b, m);
@@ -590,7 +605,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     for (int r = 0; r < G::E; ++r) (res + G::idxA(r, 0))[u32(tid)] = hxf::from_f64(atA[G::pad(G::idxA(r, 0))]);
 }
 
-template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false, bool DL = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
@@ -640,6 +655,104 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     const u32 first = i == 0 ? 1u : 0u;
     double acc0[G::E], acc1[G::E];
     double v[G::E];                                               // between rounds: the next round's input, A order
+    // DL ("diagonal late", L >= 2 only; the launcher picks it): the d == i term as the LAST multiply-accumulate of the mod-up instead of
+    // a phase of its own at the start. A workgroup that starts with that term waits for 512 KiB (t_i, its two key rows, the first
+    // c_d) with nothing else to do -- 17 k cycles for 3.6 k of issue (tools/ksx_timeline); here it starts on the 128 KiB of the first
+    // c_d, the raw t_i words arrive as the "next input" of the last round's multiply-accumulate (at their B positions: the product
+    // is element-wise) and the term goes through the key ring like every other, beside the other waves' transforms.
+    if constexpr (DL) {
+        static_assert(!FUSED && G::KL <= 2, "direct B-order loads of t_i");
+        const u64* ti = a.t_target + (size_t(bt) * L + i) * G::N;
+        {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            KX_STAMP(60);
+            const RowStream<double> in(round_src(first), G::N * 8);
+            const u32 toff = u32(tid) * 8;
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = in.at(toff, G::idxA(r, 0) * 8); }
+            KX_STAMP(61);
+        }
+        const u32 last = i == L - 1 ? L - 2 : L - 1;                  // the last d != i
+        // rounds d != i except the last: acc += NTT(c_d mod q_i) . key[d][i]
+#if KX_DL_SELECT
+        // (one loop over ALL d != i; the last round's multiply-accumulate picks the t_i addressing at run time)
+#pragma unroll 1
+        for (u32 it = first; it < L;) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            u32 toff = KX_ALIASED(16, i) * 4 * G::N;
+            asm volatile("" : "+s"(toff));
+            const double* tb = a.tables + toff;
+            KX_STAMP(4 * it + 0);
+            if constexpr (!SKIP) {
+#pragma unroll
+                for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
+            }
+            KX_STAMP(4 * it + 1);
+            u32 nit = it + 1;
+            if (nit == i) ++nit;
+            const double* k0 = key_row<G>(a, it, i);
+            WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);
+            KX_STAMP(4 * it + 2);
+            const bool lastround = it == last;
+            mac_keys<G, LAZYFOLD, 2>(acc0, acc1, v, k0, lastround ? (const double*)ti : round_src(nit), tid, m, lastround);
+            it = nit;
+        }
+#else
+#pragma unroll 1
+        for (u32 it = first; it != last;) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            u32 toff = KX_ALIASED(16, i) * 4 * G::N;
+            asm volatile("" : "+s"(toff));
+            const double* tb = a.tables + toff;
+            KX_STAMP(4 * it + 0);
+            if constexpr (!SKIP) {
+#pragma unroll
+                for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);             // intt1_redu.hpp:36-42
+            }
+            KX_STAMP(4 * it + 1);
+            u32 nit = it + 1;
+            if (nit == i) ++nit;
+            const double* k0 = key_row<G>(a, it, i);
+            WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);         // |u| <= 2.14p (SKIP: 3.45p)
+            KX_STAMP(4 * it + 2);
+            mac_keys<G, LAZYFOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);
+            it = nit;
+        }
+        {   // the last d != i: its multiply-accumulate brings in the raw t_i words
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            u32 toff = KX_ALIASED(16, i) * 4 * G::N;
+            asm volatile("" : "+s"(toff));
+            const double* tb = a.tables + toff;
+            KX_STAMP(4 * last + 0);
+            if constexpr (!SKIP) {
+#pragma unroll
+                for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
+            }
+            KX_STAMP(4 * last + 1);
+            WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);
+            KX_STAMP(4 * last + 2);
+            mac_keys<G, LAZYFOLD, 1, KX_DL_PF>(acc0, acc1, v, key_row<G>(a, last, i), (const double*)ti, tid, m);
+        }
+#endif
+        {   // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            KX_STAMP(4 * i + 0);
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) {
+                u64 bits;
+                __builtin_memcpy(&bits, &v[r], 8);
+                if constexpr (LAZYFOLD) v[r] = hxf::to_f64_lt52(bits);              // t_i < q_i as it comes: mac_fold takes |x| <= 3.45p
+                else v[r] = hxf::reduce(hxf::to_f64_lt52(bits), m);                  // (k_ksx_intt has range-checked these very words)
+            }
+            KX_STAMP(4 * i + 2);
+            mac_keys<G, LAZYFOLD, 0, KX_DL_PF>(acc0, acc1, v, key_row<G>(a, i, i), round_src(L), tid, m);   // s'_0 follows
+        }
+    } else {
     {
         // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
         int tid = threadIdx.x;
@@ -685,6 +798,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         mac_keys<G, LAZYFOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
         it = nit;
     }
+    }
     // (lazy kernels: the accumulators stay as mac_fold leaves them, |acc| <= 1.7p -- ksx_down_round)
     // rounds L, L+1 (k = 0, 1)
     hxf::RangeMask bad = 0;                                             // a result word >= its modulus (FP64 precondition)
@@ -719,6 +833,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
 }
 
 // ---------------------------------------------------------------------------------------------
+// HEXL_KSX_DIAG=0: k_ksx_main starts with the d == i term as in rounds 2-3 (tests, comparisons)
+static bool diag_late_enabled() {
+    static const bool on = [] { const char* e = getenv("HEXL_KSX_DIAG"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 template <class K>
 static int set_lds_x(K kern, size_t bytes) {
     HX_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -728,11 +848,14 @@ static int set_lds_x(K kern, size_t bytes) {
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
 static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
     using G = Geom<LOGN, LOGE>;
+    // the d == i term as the last multiply-accumulate of the mod-up (k_ksx_main<..., DL>): N = 16384 only (measured there), L >= 2
+    constexpr bool CAN_DL = KX_DIAG_LATE && !FUSED && LOGN == 14 && LOGE == 4;
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
             int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY, SKIP>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksx_intt<LOGN, LOGE, LAZY, FUSED>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>, G::LDS_USED);
+            if constexpr (CAN_DL) if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP, true>, G::LDS_USED);
             return rc;
         }))
         return rc0;
@@ -754,9 +877,13 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
     if (stage_mask & 2)
         hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY, SKIP>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
-    if (stage_mask & 4)
-        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>), KX_MAIN_PERSIST ? grid_for(a.nb * a.L) : dim3(a.nb * a.L), dim3(G::T),
-                           G::LDS_USED, st, a);
+    if (stage_mask & 4) {
+        const dim3 grid = KX_MAIN_PERSIST ? grid_for(a.nb * a.L) : dim3(a.nb * a.L);
+        bool dl = false;
+        if constexpr (CAN_DL) dl = a.L >= 2 && diag_late_enabled();
+        if constexpr (CAN_DL) if (dl) hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP, true>), grid, dim3(G::T), G::LDS_USED, st, a);
+        if (!dl) hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>), grid, dim3(G::T), G::LDS_USED, st, a);
+    }
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }
