@@ -62,7 +62,8 @@ def device_inputs(hx, orc_mod, case, batch, dev, distinct=None):
 
 # the three standalone-NTT workloads reported at N = 16384 (all fwd + inv):
 NTT_Q_FAST = None                   # primes(1, 51, N)[0] = 2251799814045697: q in (2^51, 2^52), genuine Shoup tables -> exact FP64 fast path
-NTT_Q_SURVEY = 4503599627763713     # SURVEY 8d cfg1/cfg2's prime, 2^52 + 393217: outside the FP64 range -> integer Harvey kernels
+NTT_Q_SURVEY = 4503599627763713     # SURVEY 8d cfg1/cfg2's prime, 2^52 + 393217: above the lazy FP64 range -> STRICT FP64 kernels (moduli < 2^52 * 1.125)
+NTT_BITS_INTEGER = 59               # a modulus only the integer Harvey kernels take (>= 2^52 * 1.125)
 NTT_Q_REFBENCH = 136314881          # benchmark/bench_fwd_ntt.cpp:28-42, bench_inv_ntt.cpp: RANDOM roots / precons / inv_n -> integer butterflies
 
 
@@ -559,9 +560,11 @@ def main():
             out["ntt_config"] = f"N={N}, q={ntt['q']} (51-bit, exact FP64 fast path), batch 1024 per GPU per launch, {world} GPU(s)"
         if not a.no_extra and world == 1:
             extra["ntt_N16384_batch4096"] = time_ntt(hx, ctx, orc_mod, dev, 4096, 100)      # launch overhead amortised over 4x the work
-            # the two slower standalone-NTT paths, same shape: SURVEY 8d's own prime (2^52 + 393217 is above the FP64 range: integer
-            # Harvey kernels) and the reference benchmark's workload (random tables: integer butterflies inside the persistent kernel)
-            extra["ntt_N16384_batch1024_q_2p52_integer_kernels"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=NTT_Q_SURVEY)
+            # the slower standalone-NTT paths, same shape: SURVEY 8d's own prime (2^52 + 393217 is above the LAZY FP64 range: strict
+            # FP64 kernels since round 4 -- integer Harvey kernels before), a 59-bit prime (integer Harvey kernels) and the reference
+            # benchmark's workload (random tables: integer kernels through the host hint)
+            extra["ntt_N16384_batch1024_q_2p52_plus_393217_strict_fp64"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=NTT_Q_SURVEY)
+            extra["ntt_N16384_batch1024_59bit_prime_integer_kernels"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=orc_mod.primes(1, NTT_BITS_INTEGER, N)[0])
             extra["ntt_N16384_batch1024_refbench_random_tables"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=NTT_Q_REFBENCH, random_tables=True)
             extra["cxx_api_end_to_end"] = cxx_api_end_to_end(6)
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)

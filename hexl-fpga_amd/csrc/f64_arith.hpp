@@ -83,6 +83,20 @@ HX_HD uint64_t from_f64(double x) {
     return b & 0x000FFFFFFFFFFFFFull;
 }
 
+// The STRICT butterflies (every value reduced after every operation) leave room above 2^52: the largest intermediate is the
+// inverse butterfly's |h - k p| <= (1.31 + 0.22) p for |d| = |X - Y| <= p + 4 (quotient from the product: three roundings of a
+// value near p/2, ulp 1/2), the forward's |X + t| <= 1.4 p, all below 2^53 up to p ~ 2^52.39. The standalone _NTT / _INTT fast
+// path (ntt.hip) takes moduli up to 2^52 * 1.125 on them -- SURVEY 8d's q = 2^52 + 393217 among them -- which only needs word
+// <-> double conversions that do not assume 52 bits. tests/cpp/f64_selftest.cpp replays both transforms at the bound against
+// the oracle and tracks the largest magnitude.
+constexpr uint64_t STRICT_NTT_MAX_Q = 5066549580791808ull;      // 2^52 * 1.125
+// an integer 0 <= x < 2^53 held in a double -> uint64 (from_f64 needs x < 2^52)
+HX_HD uint64_t from_f64_53(double x) {
+    const double hi = __builtin_floor(x * (1.0 / 4294967296.0));
+    const double lo = __builtin_fma(-hi, 4294967296.0, x);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
+}
+
 // The precondition of the FP64 kernels -- every input word below its modulus -- checked where the word is converted anyway:
 // one compare per word (NaN-safe form; words >= 2^53 convert inexactly but stay >= p), collected as a wave-uniform lane mask
 // (compare into a scalar register pair + scalar OR: no vector registers). The kernels OR the outcome into a per-plan flag

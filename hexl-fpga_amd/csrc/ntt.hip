@@ -98,7 +98,30 @@ struct NttHint { unsigned long long* word; unsigned long long tag; };
 template <int LAZY>
 __device__ __forceinline__ u64 fast_path_limit(u64 q, bool forward) {
     if constexpr (LAZY != 0) { const u64 l = q + (q >> 2); return l < (1ull << 52) ? l : (1ull << 52); }
-    else return forward ? ((q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53)) : (q << 1);
+    else return forward ? ((q << 2) < (1ull << 53) ? (q << 2) : (1ull << 53)) : ((q << 1) < (1ull << 53) ? (q << 1) : (1ull << 53));
+}
+// canonical result word of a fast-path transform. The strict kernels also serve moduli in [2^52, STRICT_NTT_MAX_Q) (f64_arith.hpp),
+// whose residues need the conversion that does not assume 52 bits (`wide`, wave-uniform)
+// (one wave-uniform branch around the whole store loop, not one per word)
+template <int LAZY, class At>
+__device__ __forceinline__ void fast_path_store(const double (&f)[1 << 4], u64* px, const Mod m, u64 q, At at) {
+    if (LAZY == 0 && q >= (1ull << 52)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) px[at(r)] = hxf::from_f64_53(hxf::lift(f[r], m));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) px[at(r)] = hxf::from_f64(hxf::lift(f[r], m));
+    }
+}
+template <int LAZY, class At>
+__device__ __forceinline__ void fast_path_store(const double (&f)[1 << 5], u64* px, const Mod m, u64 q, At at) {
+    if (LAZY == 0 && q >= (1ull << 52)) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) px[at(r)] = hxf::from_f64_53(hxf::lift(f[r], m));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) px[at(r)] = hxf::from_f64(hxf::lift(f[r], m));
+    }
 }
 template <int LAZY>
 __device__ __forceinline__ double fast_path_input(u64 raw, const Mod m) {
@@ -141,8 +164,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+        fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
     } else {
         slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
     }
@@ -179,8 +201,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
     WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
     const bool slow = __syncthreads_or(out_of_range);                            // see k_ntt_fwd_x
     if (!slow) {
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+        fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
     } else {
         slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
     }
@@ -271,8 +292,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
-#pragma unroll
-            for (int r = 0; r < G::E; ++r) px[G::idxB(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+            fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
         } else {
             slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
             __syncthreads();
@@ -333,8 +353,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         });
         const bool slow = vote.result(tid);
         if (!slow) {
-#pragma unroll
-            for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = hxf::from_f64(hxf::lift(f[r], m));
+            fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
         } else {
             slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
             __syncthreads();
@@ -641,7 +660,7 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
     if (!batch) return 0;
     const int logn = ilog2_exact(n);
     ctx->ntt_clear_viol = nullptr;
-    if (fast_path_enabled() && q >= (1ull << 16) && q < (1ull << 52)) {
+    if (fast_path_enabled() && q >= (1ull << 16) && q < hxf::STRICT_NTT_MAX_Q) {
         double *w, *wp; u32* viol;
         int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol);
         if (rc) return rc;
@@ -675,7 +694,7 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
     if (!batch) return 0;
     const int logn = ilog2_exact(n);
     ctx->ntt_clear_viol = nullptr;
-    if (fast_path_enabled() && q >= (1ull << 16) && q < (1ull << 52) && a < q && b < q) {
+    if (fast_path_enabled() && q >= (1ull << 16) && q < hxf::STRICT_NTT_MAX_Q && a < q && b < q) {
         double *w, *wp; u32* viol;
         int rc = prepare_tables(ctx, ir, ip, q, n, &w, &wp, &viol);
         if (rc) return rc;

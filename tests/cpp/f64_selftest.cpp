@@ -339,6 +339,97 @@ static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversaria
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "nowp inverse n=%lu p=%lu lazy=%d i=%lu", n, p, (int)lazy, i);
 }
 
+// STRICT butterflies at moduli in [2^52, STRICT_NTT_MAX_Q) -- the standalone _NTT / _INTT fast path of ntt.hip for SURVEY 8d's
+// q = 2^52 + 393217: forward (ct_bfly) and table-free inverse (gs_bfly_nowp, fused last stage on mul_shoup) with the device's own
+// conversions (reduce(to_f64(raw)) in, from_f64_53(lift()) out), against the oracle, tracking every intermediate magnitude
+static double g_wide_max = 0;
+static inline void trackw(double x) { double a = x < 0 ? -x : x; if (a > g_wide_max) g_wide_max = a; }
+static void test_strict_wide(uint64_t n, uint64_t p, bool adversarial) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t *inv0 = blk.data(), *roots = blk.data() + 2 * n;
+    auto centre = [&](uint64_t v) { return v > p / 2 ? (double)v - (double)p : (double)v; };      // k_ntt_prepare
+    std::vector<uint64_t> x(n), ref;
+    orc_fill_splitmix(x.data(), n, p ^ (n + 7), p);
+    if (adversarial) for (uint64_t i = 0; i < n; ++i) x[i] = (i & 1) ? p - 1 : ((i & 2) ? p / 2 + 1 : p / 2);
+    // word <-> double conversions at the top of the range
+    for (uint64_t v : {p - 1, p - 2, (uint64_t)1 << 52, ((uint64_t)1 << 52) + 1, ((uint64_t)1 << 52) - 1, (uint64_t)0, (uint64_t)1, p / 2})
+        CHECK(hxf::from_f64_53(hxf::to_f64(v)) == v, "from_f64_53 %lu", v);
+    for (int i = 0; i < 100000; ++i) { const uint64_t v = rnd() >> 11; CHECK(hxf::from_f64_53(hxf::to_f64(v)) == v, "from_f64_53 %lu", v); }
+    // forward
+    ref = x; orc_ks_ntt(ref.data(), n, p, roots);
+    std::vector<double> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = hxf::reduce(hxf::to_f64(x[i]), m);
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1)
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                const double tt = hxf::mul_mod(v[j + t], w, m);
+                trackw(tt); trackw(v[j] + tt); trackw(v[j] - tt);
+                hxf::ct_bfly(v[j], v[j + t], w, m);
+                trackw(v[j]); trackw(v[j + t]);
+            }
+        }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64_53(hxf::lift(v[i], m)) == ref[i], "wide fwd n=%lu p=%lu i=%lu", n, p, i);
+    // inverse, table-free, fused last stage
+    ref = x; orc_ks_intt(ref.data(), n, p, inv0);
+    for (uint64_t i = 0; i < n; ++i) v[i] = hxf::reduce(hxf::to_f64(x[i]), m);
+    const double ninv = centre(orc_invmod(n, p)), ninv_p = ninv / (double)p;
+    const double nw = centre(orc_mulmod(orc_invmod(n, p), inv0[n - 2], p)), nw_p = nw / (double)p;
+    uint64_t acc = 0;
+    for (uint64_t mm = n >> 1, t = 1; mm >= 1; mm >>= 1, t <<= 1) {
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(inv0[acc + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                const double sum = v[j] + v[j + t], dif = v[j] - v[j + t];
+                trackw(sum); trackw(dif);
+                if (mm > 1) {
+                    trackw(hxf::mul_mod(dif, w, m));
+                    hxf::gs_bfly_nowp(v[j], v[j + t], w, m);
+                } else {
+                    const double a = hxf::mul_shoup(sum, ninv, ninv_p, m), b = hxf::mul_shoup(dif, nw, nw_p, m);
+                    trackw(a); trackw(b);
+                    v[j] = hxf::reduce(a, m);
+                    v[j + t] = hxf::reduce(b, m);
+                }
+                trackw(v[j]); trackw(v[j + t]);
+            }
+        }
+        acc += mm;
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64_53(hxf::lift(v[i], m)) == ref[i], "wide inv n=%lu p=%lu i=%lu", n, p, i);
+}
+// the products inside mul_mod / mul_shoup at such a modulus: |h - k p| must stay below 2^53 (exactness of the fma)
+static void test_prime_wide(uint64_t p) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    const int64_t P = (int64_t)p;
+    for (int it = 0; it < 400000; ++it) {
+        const bool edge = (it & 3) == 0;
+        auto pick = [&](int64_t bound) -> int64_t {
+            if (edge) { const int64_t e[6] = {bound, -bound, bound - 1, -(bound - 1), bound / 2, 1}; return e[rnd() % 6]; }
+            return (int64_t)(rnd() % (2 * (uint64_t)bound + 1)) - bound;
+        };
+        // forward: |y| <= p/2 + 2, |w| <= p/2;   inverse: |d| <= p + 4
+        for (int64_t bound : {P / 2 + 2, P + 4}) {
+            const int64_t a = pick(bound), w = pick(P / 2);
+            const double h = (double)a * (double)w, k = __builtin_rint(h * m.pinv);
+            const double hk = __builtin_fma(-k, m.p, h);
+            trackw(hk);
+            const double u = hxf::mul_mod((double)a, (double)w, m);
+            CHECK(u == (double)(int64_t)u && centred((i128)a * w - (int64_t)u, P) == 0, "wide mul_mod p=%lu a=%ld w=%ld u=%.0f", p, a, w, u);
+            trackw(u);
+            const double r = hxf::reduce(u, m);
+            CHECK((int64_t)r >= -(P / 2) - 2 && (int64_t)r <= P / 2 + 2 && centred((i128)a * w - (int64_t)r, P) == 0, "wide reduce p=%lu", p);
+        }
+        const int64_t c = pick(P / 2 + 2);
+        CHECK(hxf::lift((double)c, m) == (double)centred(c, P), "wide lift p=%lu c=%ld", p, c);
+        const uint64_t raw = rnd() % ((uint64_t)1 << 53);
+        const double rr = hxf::reduce(hxf::to_f64(raw), m);
+        CHECK((int64_t)rr >= -(P / 2) - 2 && (int64_t)rr <= P / 2 + 2 && centred((i128)raw - (int64_t)rr, P) == 0, "wide input reduce p=%lu raw=%lu", p, raw);
+    }
+}
+
 int main() {
     std::vector<uint64_t> primes;
     uint64_t tmp[8];
@@ -400,6 +491,19 @@ int main() {
     // strict kernels (moduli up to 2^52): table-free inverse with both outputs reduced
     for (uint64_t p : primes)
         for (uint64_t n : {1024ull, 16384ull}) { test_inverse_nowp(n, p, false, false); test_inverse_nowp(n, p, false, true); }
+    // strict kernels above 2^52 (standalone _NTT / _INTT only): SURVEY 8d's prime and the largest admissible one = 1 mod 2^15
+    {
+        std::vector<uint64_t> wide = {4503599627763713ull};
+        for (uint64_t v = ((hxf::STRICT_NTT_MAX_Q - 1) / 32768) * 32768 + 1; wide.size() < 2 && v > (1ull << 52); v -= 32768)
+            if (v < hxf::STRICT_NTT_MAX_Q && orc_is_prime(v)) wide.push_back(v);
+        for (uint64_t p : wide) {
+            CHECK(orc_is_prime(p) && p % 32768 == 1 && p >= (1ull << 52) && p < hxf::STRICT_NTT_MAX_Q, "wide prime %lu", p);
+            test_prime_wide(p);
+            for (uint64_t n : {1024ull, 16384ull}) { test_strict_wide(n, p, false); test_strict_wide(n, p, true); }
+        }
+        std::printf("strict kernels at 2^52 <= p < 2^52 * 1.125 (%lu, %lu): max |x| seen = 2^%.3f (limit 2^53)\n", wide[0], wide.back(), log2(g_wide_max));
+        CHECK(g_wide_max < 9007199254740992.0, "strict wide bound exceeded");
+    }
     std::printf("folded multiply-accumulate: max |acc| / p seen = %.3f (bound 1.6)\n", g_fold_max);
     std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());
     return failures ? 1 : 0;

@@ -298,3 +298,46 @@ def test_tables_edited_in_place_between_calls(hx, ctx, dev, orc, n, batch):
         check(edit=pos); check(edit=pos)                         # stale cache detected by the kernel, then verified again
         tabs[0][pos] ^= one; tabs[2][pos] ^= one
         check(); check()
+
+
+def _wide_primes(orc, n):
+    """SURVEY 8d's q = 2^52 + 393217 and the largest prime = 1 mod 2^15 below 2^52 * 1.125 (f64_arith.hpp STRICT_NTT_MAX_Q)"""
+    top = (1 << 52) + (1 << 49)
+    v = ((top - 1) // 32768) * 32768 + 1
+    while not orc.orc().orc_is_prime(v):
+        v -= 32768
+    return [4503599627763713, v]
+
+
+@pytest.mark.parametrize("which", [0, 1], ids=["q_2p52_plus_393217", "largest_below_2p52_x_1p125"])
+@pytest.mark.parametrize("n", [16384, 4096])
+def test_moduli_just_above_2p52_take_the_strict_fp64_path(hx, ctx, dev, orc, which, n):
+    """Moduli in [2^52, 2^52 * 1.125) -- SURVEY 8d pins q = 4503599627763713 for configs 1-2 -- run the STRICT FP64 transforms
+    (ntt.hip, f64_arith.hpp STRICT_NTT_MAX_Q; round 4) instead of the integer Harvey kernels: the reference's stimulus matrix,
+    canonical random batches large enough for the persistent kernels, words in [q, 4q) below and above 2^53 (the latter take
+    the integer fallback inside the same launch), all bit-exact against the oracle's op-for-op replay"""
+    q = _wide_primes(orc, n)[which]
+    assert orc.orc().orc_is_prime(q) and q % (2 * n) == 1 and (1 << 52) <= q < (1 << 52) + (1 << 49)
+    t = orc.HexlTables(n, q)
+    x = np.stack([stimulus(k, n, q) for k in STIMS])
+    assert np.array_equal(run_fwd(hx, ctx, dev, x, t), orc.ntt_fwd(x, t))
+    assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t))
+    # a persistent-kernel batch of canonical polynomials; every fifth one carries a word in [q, 2^53) (still the fast path,
+    # forward) or in [2^53, 4q) (integer fallback), every eleventh the largest canonical words
+    batch = 3000 * 1024 // n + 5
+    base = np.stack([orc.splitmix(n, 70 + b, q) for b in range(4)])
+    base[3, :8] = np.array([q - 1, q - 2, (1 << 52), (1 << 52) + 1, (1 << 52) - 1, 0, 1, q // 2], dtype=np.uint64)
+    x = base[np.arange(batch) % 4].copy()
+    odd = np.arange(2, batch, 5)
+    x[odd, (odd * 40503) % n] = np.where(odd % 2 == 0, np.uint64((1 << 53) - 7), np.uint64(min(4 * q - 3, (1 << 63) + 11)))
+    for fwd in (True, False):
+        got = (run_fwd if fwd else run_inv)(hx, ctx, dev, x, t)
+        ref4 = (orc.ntt_fwd if fwd else orc.ntt_inv)(base, t)
+        clean = np.setdiff1d(np.arange(batch), odd)
+        assert (got[clean] == ref4[clean % 4]).all(), "canonical polynomials"
+        sample = odd[:: max(1, len(odd) // 16)]
+        want = (orc.ntt_fwd if fwd else orc.ntt_inv)(x[sample], t)
+        assert np.array_equal(got[sample], want), "polynomials with out-of-range words"
+    # round trip at full batch
+    y = run_inv(hx, ctx, dev, run_fwd(hx, ctx, dev, base, t), t)
+    assert np.array_equal(y, base)
