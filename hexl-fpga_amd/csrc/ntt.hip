@@ -17,9 +17,18 @@
 #ifndef HX_IINV_PRIO
 #define HX_IINV_PRIO 2212
 #endif
+#ifndef HX_IFWD_PRIO
+#define HX_IFWD_PRIO 1222
+#endif
+#ifndef HX_IFWD_PERSIST_DEFAULT
+#define HX_IFWD_PERSIST_DEFAULT 0
+#endif
 #include "hexl_internal.hpp"
 #include "ntt_core.hpp"
 #include "ntt_core_f64.hpp"
+
+// (N = 2048 -- 128-thread workgroups of two waves -- measured 3 % slower with the priorities: off there)
+constexpr int ntt_fwd_prio(int logn) { return logn == 11 ? 0 : HX_FWD_PRIO; }
 
 using namespace hx;
 
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -481,6 +490,45 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_ip(u64* __restri
     }
 }
 
+// The forward counterpart (round 4, with the wave priorities of HX_IFWD_PRIO: a persistent forward integer kernel measured slower
+// than one workgroup per polynomial in round 2 and was dropped then). The next polynomial is requested at the top of the current
+// transform, whose first two passes take their twiddles through the scalar cache.
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_ip(u64* __restrict__ x, const u64* __restrict__ roots,
+                                                                   const u64* __restrict__ precon, u64 q, u32 batch,
+                                                                   const u32* __restrict__ viol = nullptr,
+                                                                   unsigned long long* hint_word = nullptr) {
+    using G = Geom<LOGN, LOGE>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    if (hint_word && blockIdx.x == 0 && threadIdx.x == 0 && *viol == 0) *hint_word = 0;      // see k_ntt_fwd
+    u64 raw[G::E];
+    {
+        const int tid = threadIdx.x;
+        const u64* p0 = x + size_t(blockIdx.x) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
+    }
+#pragma unroll 1
+    for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u64* px = x + size_t(p) * G::N;
+        u64 v[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = raw[r];
+        const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;
+        const u64* pnx = x + size_t(pn) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
+        const u64* tw = roots + opaque_zero();
+        WgNtt<LOGN, LOGE>::forward_lazy(v, lds, tid, tw, precon + (tw - roots), q);
+        WgNtt<LOGN, LOGE>::final_reduce(v, q);
+        const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) (px + G::idxB(r, 0))[tB] = v[r];
+    }
+}
+
 u32 hx_loge_for(u32 logn) {
     static const int forced = [] { const char* e = getenv("HEXL_NTT_LOGE"); return e ? atoi(e) : 0; }();
     // N = 16384: 16 coefficients per thread x 1024 threads (4 waves/SIMD) measured ~10 % faster than 32 x 512
@@ -505,6 +553,20 @@ static int launch_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
             return 0;
         }))
         return rc;
+    // HEXL_NTT_IFWD_PERSIST=1: the persistent forward integer kernel (experiment)
+    static const int persist = [] { const char* e = getenv("HEXL_NTT_IFWD_PERSIST"); return e ? atoi(e) : HX_IFWD_PERSIST_DEFAULT; }();
+    const size_t slots = size_t(ctx->num_cu) * (G::LDS_USED > 80 * 1024 ? 1 : (160 * 1024) / G::LDS_USED);
+    if constexpr (LOGN == 14 && LOGE == 4) if (persist && batch > slots) {
+        static PerDeviceOnce once_p;
+        if (int rc = once_p.run(ctx->device, [] {
+                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_ip<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+                return 0;
+            }))
+            return rc;
+        hipLaunchKernelGGL((k_ntt_fwd_ip<LOGN, LOGE>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x, roots, precon,
+                           q, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((k_ntt_fwd<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
     return (int)hipGetLastError();
