@@ -627,6 +627,17 @@ def main():
             # the smaller ring dimensions the reference's KeySwitch accepts (host/src/keyswitch.cpp:23-25), decomp 3 / 4 key moduli
             for nx in (8192, 4096, 1024):
                 extra["keyswitch_%d_3_4_4_2" % nx] = other_shape(3, 4, None, nx)
+            # the headline shape with the LARGEST 52-bit primes = 1 mod 2N (what SEAL's CoeffModulus::Create(n, {52, ...}) picks; `value`
+            # uses the smallest ones): above the lazy bound 2^51 (1 + 2^-7), i.e. the STRICT FP64 kernels, 14 instead of 8-11
+            # instructions per butterfly -- the slower reading of "52-bit primes", reported beside the faster one
+            def largest_52bit_primes(count):
+                out_, v = [], (1 << 52) - 2 * N + 1
+                while len(out_) < count:
+                    if orc_mod.orc().orc_is_prime(v):
+                        out_.append(v)
+                    v -= 2 * N
+                return out_
+            extra["keyswitch_16384_L%d_largest_52bit_primes_strict_kernels" % L] = other_shape(L, L + 1, largest_52bit_primes(L + 1))
             # the headline shape on the 64-bit INTEGER kernels (59-bit primes: beyond the reference's < 2^52 envelope)
             extra["keyswitch_16384_L%d_59bit_primes_integer_kernels" % L] = other_shape(L, L + 1, orc_mod.primes(L + 1, 59, N))
         out["extra"] = extra

@@ -191,6 +191,9 @@ HX_HD void gs_bfly_nowp(double& X, double& Y, double w, const Mod m) {     // bo
 //   K differs from (x k + acc)/p by at most 0.5 + (three roundings of a value < 2^52: 0.75) + |l|/p  =>  |acc'| <= 1.6p
 //   exact: acc + l is an integer below 1.6p + 2^49 < 2^52; |h - K p| <= |acc'| + |acc + l| < 3.4p < 2^53; acc' an integer < 2^53.
 // tests/cpp/f64_selftest.cpp replays chains of it against 128-bit integers at extreme operands for every tier.
+// STRICT tier (moduli up to 2^52, transform output reduced: |x| <= p/2 + 2, |k| <= p/2): the quotient estimate is off by at most
+// 0.5 + three roundings of a value below 2^50 (ulp 1/4: 0.375)  =>  |acc'| <= 0.875p + |l| whatever the accumulator was; exact:
+// |acc + l| <= 0.9p + 2^48 < 2^53, |h - K p| <= |acc'| + |acc + l| <= 1.8p < 2^53. The consumer of the last term reduces once.
 HX_HD double mac_fold(double acc, double x, double k, const Mod m) {
     const double h = x * k;
     const double l = __builtin_fma(x, k, -h);

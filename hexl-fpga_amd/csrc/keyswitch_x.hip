@@ -226,6 +226,9 @@ constexpr int KX_PF = KX_PF_DEPTH;
 // The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads (RowStream, ntt_core.hpp).
 // acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
 // input, A order (never null)
+#ifndef KX_STRICT_FOLD
+#define KX_STRICT_FOLD 1   // strict kernels (moduli above the lazy bound, up to 2^52): folded multiply-accumulate as well
+#endif
 #ifndef KX_FOLD
 #define KX_FOLD 1     // lazy kernels: folded multiply-accumulate (f64_arith.hpp mac_fold), accumulators <= 1.6p between rounds
 #endif
@@ -455,9 +458,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
         KX_STAMP(4 * it + 2);
-        mac_keys<G, (LAZY != 0 && KX_FOLD)>(acc0, acc1, v, k0, a.c + (size_t(KX_ALIASED(2, b)) * L + nd) * G::N, tid, msp.m);
+        mac_keys<G, (KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD))>(acc0, acc1, v, k0, a.c + (size_t(KX_ALIASED(2, b)) * L + nd) * G::N, tid, msp.m);
     }
-    if constexpr (LAZY != 0 && KX_FOLD) {
+    if constexpr (KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD)) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
     }
@@ -612,6 +615,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;                    // mod-down transforms: centred input
     using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0>;     // mod-up transforms (SKIP: canonical c_d as it is)
     constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
+    // the strict kernels (moduli up to 2^52) fold their multiply-accumulate too (round 4; f64_arith.hpp mac_fold "strict tier": transform
+    // output |x| <= p/2 + 2, accumulators <= 0.9p between terms) and reduce the accumulators once in front of the mod-down, whose
+    // epilogue needs them centred at this modulus size; the d == i term keeps its reduced form there
+    constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
 #if KX_PRIO_MASK
     // experiment: static priority for half of the waves of every SIMD (a workgroup's waves go to the SIMDs cyclically, so waves
@@ -795,11 +802,15 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* k0 = key_row<G>(a, it, i);
         WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);         // |u| <= 2.14p (SKIP: 3.45p)
         KX_STAMP(4 * it + 2);
-        mac_keys<G, LAZYFOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
+        mac_keys<G, FOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);               // nit <= L: s'_0 follows the last c_d
         it = nit;
     }
     }
     // (lazy kernels: the accumulators stay as mac_fold leaves them, |acc| <= 1.7p -- ksx_down_round)
+    if constexpr (FOLD && LAZY == 0) {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
+    }
     // rounds L, L+1 (k = 0, 1)
     hxf::RangeMask bad = 0;                                             // a result word >= its modulus (FP64 precondition)
     {

@@ -102,6 +102,48 @@ static void test_transforms(uint64_t n, uint64_t p) {
 // chains of the folded multiply-accumulate (mac_fold) against exact integers: x up to the un-reduced transform bound of the
 // tier, keys up to p/2, both random and pinned at the extremes with the signs that push the accumulator outwards
 static double g_fold_max = 0;
+static double g_fold_strict_max = 0, g_fold_strict_inner = 0;
+// the STRICT tier of mac_fold (keyswitch_x.hip KX_STRICT_FOLD): moduli up to 2^52, x a reduced transform output, the first accumulator
+// the reduced d == i term; tracks the accumulator and the two intermediates whose exactness the fma / the addition rely on
+static void test_mac_fold_strict(uint64_t p) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    const int64_t P = (int64_t)p;
+    const int64_t xmax = P / 2 + 2, kmax = P / 2;
+    for (int chain = 0; chain < 40000; ++chain) {
+        int64_t a0 = (int64_t)(rnd() % (uint64_t)(P + 5)) - (P / 2 + 2);
+        if (chain % 8 == 1) a0 = P / 2 + 2; else if (chain % 8 == 2) a0 = -(P / 2 + 2);
+        double acc = (double)a0;
+        i128 exact = a0;
+        const int mode = chain % 4;
+        for (int term = 0; term < 16; ++term) {
+            int64_t x, k;
+            if (mode == 0) { x = (int64_t)(rnd() % (2 * (uint64_t)xmax + 1)) - xmax; k = (int64_t)(rnd() % (2 * (uint64_t)kmax + 1)) - kmax; }
+            else {
+                x = xmax - (int64_t)(rnd() % 1024); k = kmax - (int64_t)(rnd() % 1024);
+                const bool up = mode == 1 ? true : mode == 2 ? (acc >= 0) : (term & 1);
+                if (!up) x = -x;
+                if (rnd() & 1) { x = -x; k = -k; }
+            }
+            {   // the intermediates of mac_fold, replayed
+                const double h = (double)x * (double)k, l = __builtin_fma((double)x, (double)k, -h);
+                const double K = __builtin_rint(__builtin_fma(acc, m.pinv, h * m.pinv));
+                const double inner = __builtin_fma(-K, m.p, h), sum = acc + l;
+                const double ai = inner < 0 ? -inner : inner, as = sum < 0 ? -sum : sum;
+                if (ai > g_fold_strict_inner) g_fold_strict_inner = ai;
+                if (as > g_fold_strict_inner) g_fold_strict_inner = as;
+                CHECK(centred((i128)x * k + (i128)(int64_t)acc - (i128)(int64_t)K * P - (i128)(int64_t)inner - (i128)(int64_t)sum, P) == 0 || true, "unused");
+            }
+            acc = hxf::mac_fold(acc, (double)x, (double)k, m);
+            exact += (i128)x * k;
+            const double a = acc < 0 ? -acc : acc;
+            if (a / (double)p > g_fold_strict_max) g_fold_strict_max = a / (double)p;
+            CHECK(acc == (double)(int64_t)acc && centred(exact - (int64_t)acc, P) == 0 && a <= 0.9 * (double)p,
+                  "strict mac_fold p=%lu chain %d term %d acc=%.0f", p, chain, term, acc);
+        }
+        const double r = hxf::reduce(acc, m);
+        CHECK((int64_t)r >= -(P / 2) - 2 && (int64_t)r <= P / 2 + 2 && centred(exact - (int64_t)r, P) == 0, "strict mac_fold final reduce p=%lu", p);
+    }
+}
 static void test_mac_fold(uint64_t p, double c) {
     hxf::Mod m{(double)p, 1.0 / (double)p};
     const int64_t P = (int64_t)p;
@@ -491,6 +533,15 @@ int main() {
     // strict kernels (moduli up to 2^52): table-free inverse with both outputs reduced
     for (uint64_t p : primes)
         for (uint64_t n : {1024ull, 16384ull}) { test_inverse_nowp(n, p, false, false); test_inverse_nowp(n, p, false, true); }
+    // strict tier of the folded multiply-accumulate: every prime above the lazy bound, the largest 52-bit ones among them
+    {
+        int n_strict = 0;
+        for (uint64_t p : primes) if ((double)p > hxf::LAZY_MAX_MODULUS) { test_mac_fold_strict(p); ++n_strict; }
+        CHECK(n_strict >= 2, "no strict primes in the list");
+        std::printf("strict folded multiply-accumulate (%d primes): max |acc| / p = %.3f (bound 0.9), largest intermediate 2^%.3f (limit 2^53)\n",
+                    n_strict, g_fold_strict_max, log2(g_fold_strict_inner));
+        CHECK(g_fold_strict_inner < 9007199254740992.0, "strict mac_fold intermediate");
+    }
     // strict kernels above 2^52 (standalone _NTT / _INTT only): SURVEY 8d's prime and the largest admissible one = 1 mod 2^15
     {
         std::vector<uint64_t> wide = {4503599627763713ull};
