@@ -136,6 +136,22 @@ HX_HD void gs_bfly(double& X, double& Y, double w, double wp, const Mod m) {
     Y = reduce(mul_shoup(d, w, wp, m), m);                   // |product| <= p before the reduce
 }
 
+// "Semi-strict" forward butterfly for moduli ABOVE the lazy bound (up to 2^52 (1 + 2^-20), SEMI_MAX_MODULUS): the product takes
+// the Shoup form (w/p table: two roundings instead of three, |y w mod p| <= (0.5 + 0.504 |y|/p) p at p = 2^52), and the two outputs
+// are range-reduced only when the NEXT stage uses them as the ADDED operand (both outputs of a butterfly have the same role in the
+// next stage); outputs that the next stage multiplies stay as they are. Within a register pass that starts from reduced values
+// (|x| <= p/2 + 2) the multiplied operand grows as y -> 1 + 0.504 y: 0.5, 1.252, 1.631, 1.822, and the pass's last stage reduces
+// everything (|X + t| <= 0.5 + 0.5 + 0.504 * 1.822 = 1.918 p < 2^53 = 2 p). Exactness of the product: |h - k p| <= (0.5 + 0.504 *
+// 1.822) p + |l| (<= 2^50) = 1.67 p. 11 instead of 14 FP64 instructions per butterfly on average over a four-stage pass.
+// tests/cpp/f64_selftest.cpp replays whole transforms on this schedule at the largest 52-bit primes and at 2^52 + 393217.
+constexpr double SEMI_MAX_MODULUS = 4503599627370496.0 * (1.0 + 1.0 / 1048576.0);
+HX_HD void ct_bfly_semi(double& X, double& Y, double w, double wp, const Mod m, bool reduce_outputs) {
+    const double t = mul_shoup(Y, w, wp, m);
+    const double a = X + t, b = X - t;
+    X = reduce_outputs ? reduce(a, m) : a;
+    Y = reduce_outputs ? reduce(b, m) : b;
+}
+
 // ---- lazy variants for moduli p <= 2^51 * (1 + 2^-7)  ("LAZY" regime) ------------------------------------
 // Every value only has to stay an exactly representable integer, |x| < 2^53 ~ 3.97p here, which leaves room
 // to skip most range reductions:

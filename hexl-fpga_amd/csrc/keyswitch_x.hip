@@ -226,6 +226,12 @@ constexpr int KX_PF = KX_PF_DEPTH;
 // The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads (RowStream, ntt_core.hpp).
 // acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
 // input, A order (never null)
+#ifndef KX_SEMI
+#define KX_SEMI 0   // 1: strict kernels with the semi-strict forward transforms (f64_arith.hpp ct_bfly_semi: 11 instead of 14 FP64 instructions per
+                    // butterfly, reads the w/p table, no PRE requests). Bit-exact; measured 159 k against 181 k keyswitch/s at the largest 52-bit primes:
+                    // twice the per-lane twiddle loads and no early requests cost more than the instructions save (19 spilled VGPRs)
+#endif
+#define KX_SEMI_ON(LAZY) ((LAZY) == 0 && KX_SEMI != 0)
 #ifndef KX_STRICT_FOLD
 #define KX_STRICT_FOLD 1   // strict kernels (moduli above the lazy bound, up to 2^52): folded multiply-accumulate as well
 #endif
@@ -418,7 +424,7 @@ template <int LOGN, int LOGE, int LAZY, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, true>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, KX_SEMI_ON(LAZY)>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;
@@ -612,8 +618,9 @@ template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false, b
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE>;                    // mod-down transforms: centred input
-    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0>;     // mod-up transforms (SKIP: canonical c_d as it is)
+    // (strict kernels: the semi-strict forward schedule, f64_arith.hpp ct_bfly_semi -- plain twiddle loads, no PRE requests)
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY)>;               // mod-down transforms: centred input
+    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY)>;   // mod-up transforms (SKIP: canonical c_d as it is)
     constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
     // the strict kernels (moduli up to 2^52) fold their multiply-accumulate too (round 4; f64_arith.hpp mac_fold "strict tier": transform
     // output |x| <= p/2 + 2, accumulators <= 0.9p between terms) and reduce the accumulators once in front of the mod-down, whose

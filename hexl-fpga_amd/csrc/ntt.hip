@@ -58,7 +58,8 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     const double pd = (double)q;
     const u64 rr = r < q ? r : 0;
     const double c = rr > q / 2 ? (double)rr - pd : (double)rr;
-    w[i] = c;          // (no w/p table: both transforms take their quotients from the products, f64_arith.hpp)
+    w[i] = c;          // (the lazy transforms take their quotients from the products: no w/p table, f64_arith.hpp)
+    if (pd > hxf::LAZY_MAX_MODULUS) wp[i] = c / pd;                  // strict tier: the semi-strict forward schedule reads it
 }
 
 // Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
@@ -138,7 +139,7 @@ __device__ __forceinline__ double fast_path_input(u64 raw, const Mod m) {
     else return hxf::reduce(hxf::to_f64(raw), m);
 }
 
-template <int LOGN, int LOGE, int LAZY>
+template <int LOGN, int LOGE, int LAZY, bool SEMI = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restrict__ x, const u64* __restrict__ roots,
                                                                   const u64* __restrict__ precon, u64 q,
                                                                   const double* __restrict__ w,
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), SEMI>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -251,7 +252,7 @@ struct RangeVote {
 // waited for until it has landed: the first two passes take their twiddles through the scalar cache (~14 k cycles).
 // (Requested after the cross-wave re-deal instead, the first per-lane twiddle wait stalls on it:
 // tools/experiments/persistent_prefetch.patch measured that 10 % SLOWER.)
-template <int LOGN, int LOGE, int LAZY>
+template <int LOGN, int LOGE, int LAZY, bool SEMI = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restrict__ x, const u64* __restrict__ roots,
                                                                   const u64* __restrict__ precon, u64 q,
                                                                   const double* __restrict__ w,
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), SEMI>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -370,6 +371,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     }
 }
 
+static bool semi_enabled() {
+    static const bool v = [] { const char* e = getenv("HEXL_NTT_SEMI"); return e && atoi(e) == 1; }();    // measured 2-4 % slower: off
+    return v;
+}
 static bool fast_path_enabled() {
     static const bool v = [] { const char* e = getenv("HEXL_NTT_INT"); return !(e && atoi(e) == 1); }();
     return v;
@@ -600,13 +605,13 @@ static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
     return (int)hipGetLastError();
 }
 
-template <int LOGN, int LOGE, int LAZY>
+template <int LOGN, int LOGE, int LAZY, bool SEMI = false>
 static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q,
                         const double* w, const double* wp, const u32* viol) {
     using G = Geom<LOGN, LOGE>;
     static PerDeviceOnce once;
     if (int rc = once.run(ctx->device, [] {
-            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_x<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_x<LOGN, LOGE, LAZY, SEMI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
             return 0;
         }))
         return rc;
@@ -617,15 +622,15 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
     if (persist && !G::HALF_ONLY && batch > slots) {
         static PerDeviceOnce once_p;
         if (int rc = once_p.run(ctx->device, [] {
-                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_p<LOGN, LOGE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_USED + RangeVote::BYTES)));
+                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_p<LOGN, LOGE, LAZY, SEMI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_USED + RangeVote::BYTES)));
                 return 0;
             }))
             return rc;
-        hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
+        hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY, SEMI>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
                            roots, precon, q, w, wp, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
+    hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY, SEMI>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, w, wp, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
     return (int)hipGetLastError();
 }
@@ -668,19 +673,19 @@ static bool small_e16(int logn, bool fwd) {
     return (m >> (logn - 11)) & 1;
 }
 
-template <int LAZY>
+template <int LAZY, bool SEMI = false>
 static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, const double* w,
                           const double* wp, const u32* v) {
     switch (logn) {
-        case 10: return launch_fwd_x<10, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 11: return small_e16(11, true) ? launch_fwd_x<11, 4, LAZY>(c, x, batch, r, p, q, w, wp, v)
-                                   : launch_fwd_x<11, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 12: return small_e16(12, true) ? launch_fwd_x<12, 4, LAZY>(c, x, batch, r, p, q, w, wp, v)
-                                   : launch_fwd_x<12, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 13: return small_e16(13, true) ? launch_fwd_x<13, 4, LAZY>(c, x, batch, r, p, q, w, wp, v)
-                                   : launch_fwd_x<13, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 14: return launch_fwd_x<14, 4, LAZY>(c, x, batch, r, p, q, w, wp, v);
-        case 15: return launch_fwd_x<15, 5, LAZY>(c, x, batch, r, p, q, w, wp, v);    // beyond the reference: half-size exchanges
+        case 10: return launch_fwd_x<10, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
+        case 11: return small_e16(11, true) ? launch_fwd_x<11, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v)
+                                   : launch_fwd_x<11, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
+        case 12: return small_e16(12, true) ? launch_fwd_x<12, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v)
+                                   : launch_fwd_x<12, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
+        case 13: return small_e16(13, true) ? launch_fwd_x<13, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v)
+                                   : launch_fwd_x<13, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
+        case 14: return launch_fwd_x<14, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
+        case 15: return launch_fwd_x<15, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);    // beyond the reference: half-size exchanges
         default: return HEXL_E_BADARG;
     }
 }
@@ -734,8 +739,12 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
         if (!hinted) {
             if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, w, wp, viol);
             if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, w, wp, viol);
-            return period ? dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
-                          : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+            if (period) return dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+            // strict tier: the plain strict butterflies; HEXL_NTT_SEMI=1 selects the semi-strict forward schedule (f64_arith.hpp
+            // ct_bfly_semi) up to 2^52 (1 + 2^-20): bit-exact, 11 instead of 14 instructions per butterfly, but it reads the w/p table
+            // too and measured 11.2-11.8 M against 11.5-12.0 M forward NTT/s at batch 1024 (tools/experiments/README.md)
+            return semi_enabled() && (double)q <= hxf::SEMI_MAX_MODULUS ? dispatch_fwd_x<0, true>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
+                                                                        : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
         }
     }
     switch (logn) {

@@ -28,9 +28,31 @@ typedef const __attribute__((address_space(4))) double* ctw_t;
 // NORED: global stage whose PERIODIC reduction is dropped (0 = none): on the shifted schedule the last stage of a 2^14-point
 // transform is a periodic reduction point ((14 + 1) % 3 == 0); a transform whose consumer takes an un-reduced tail (FINAL = false)
 // drops it and hands over three un-reduced stages, 3.45p, instead (f64_arith.hpp)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0, int SHIFT = 0, int NORED = 0>
+// SEMI (strict kernels only, LAZY == 0): the semi-strict schedule of f64_arith.hpp ct_bfly_semi -- Shoup-form products (the w/p table
+// IS read here) and outputs reduced only where the next stage adds them; the last stage of the call reduces everything.
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0, int SHIFT = 0, int NORED = 0, bool SEMI = false>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
+    if constexpr (SEMI) {
+        static_assert(LAZY == 0 && TF == 0, "semi-strict schedule: strict kernels, no twiddle ring");
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const u32 base = (1u << (S0 - 1 + u)) + (G << u);
+#pragma unroll
+            for (int j = 0; j < (1 << u); ++j) {
+                const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j];
+                const double Wp = UNI ? ((ctw_t)wp)[base + j] : wp[base + j];
+#pragma unroll
+                for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
+                    const int a0 = OFF + (j << (K - u)) + c;
+                    // the next stage pairs (a, a + 2^(K-2-u)): bit K-2-u of c says whether these two outputs are added or multiplied there
+                    const bool added_next = (u == K - 1) || (((c >> (K - 2 - u)) & 1) == 0);
+                    hxf::ct_bfly_semi(v[a0], v[a0 + (1 << (K - 1 - u))], W, Wp, m, added_next);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
@@ -257,8 +279,9 @@ __device__ __forceinline__ void hx_inv_prio() {
 #endif
 // FSHIFT: phase of the forward reduction schedule (1: un-centred inputs, f64_arith.hpp); NOWP: inverse transforms without
 // the w/p table
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO>
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, bool SEMI = false>
 struct WgNttF64 {
+    static_assert(!SEMI || (LAZY == 0 && PRE == 0 && TF == 0), "semi-strict forward transforms: strict kernels, plain twiddle loads");
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
 
@@ -281,7 +304,7 @@ struct WgNttF64 {
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, FSHIFT>(v, Gp, w, m);
-            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT>(v, Gp, w, wp, m);
+            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT, 0, SEMI>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
                 constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;
@@ -319,7 +342,7 @@ struct WgNttF64 {
             const u32 Gbits = u32(G::grpB(GRP, tid));
             // LOGN = 0 tells the stage loop that no stage is the last one
             fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF, FSHIFT,
-                           (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? LOGN : 0>(v, Gbits, w, wp, m);
+                           (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? LOGN : 0, SEMI>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
         }
     }

@@ -442,6 +442,45 @@ static void test_strict_wide(uint64_t n, uint64_t p, bool adversarial) {
     }
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64_53(hxf::lift(v[i], m)) == ref[i], "wide inv n=%lu p=%lu i=%lu", n, p, i);
 }
+// the SEMI-STRICT forward schedule (f64_arith.hpp ct_bfly_semi, ntt_core_f64.hpp fwd_stages_f64<..., SEMI>) replayed with the device's
+// pass structure: passes of `loge` stages, the last one partial; inside a pass a butterfly's outputs are reduced only when the next
+// stage adds them (bit t/2 of the index clear), the last stage of every pass reduces everything
+static double g_semi_max = 0, g_semi_inner = 0;
+static void test_semi(uint64_t n, int loge, uint64_t p, bool adversarial) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t* roots = blk.data() + 2 * n;
+    auto centre = [&](uint64_t v) { return v > p / 2 ? (double)v - (double)p : (double)v; };
+    int logn = 0; while ((1ull << logn) < n) ++logn;
+    const int passes = (logn + loge - 1) / loge, kl = logn - (passes - 1) * loge;
+    std::vector<uint64_t> x(n), ref;
+    orc_fill_splitmix(x.data(), n, p ^ (n + 31), p);
+    if (adversarial) for (uint64_t i = 0; i < n; ++i) x[i] = (i & 1) ? p / 2 + 1 : ((i & 2) ? p / 2 : p - 1);
+    ref = x; orc_ks_ntt(ref.data(), n, p, roots);
+    std::vector<double> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = hxf::reduce(hxf::to_f64(x[i]), m);
+    int s = 1;
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
+        const int pass = (s - 1) / loge, u = (s - 1) % loge, K = pass == passes - 1 ? kl : loge;
+        const bool last_in_pass = u == K - 1;
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]), wp = w / (double)p;
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                const bool added_next = last_in_pass || ((j & (t >> 1)) == 0);
+                {   // intermediates
+                    const double h = v[j + t] * w, k = __builtin_rint(v[j + t] * wp), inner = __builtin_fma(-k, m.p, h);
+                    const double tt = hxf::mul_shoup(v[j + t], w, wp, m);
+                    for (double q : {inner, tt, v[j] + tt, v[j] - tt}) { const double a = q < 0 ? -q : q; if (a > g_semi_inner) g_semi_inner = a; }
+                }
+                hxf::ct_bfly_semi(v[j], v[j + t], w, wp, m, added_next);
+                for (double q : {v[j], v[j + t]}) { const double a = q < 0 ? -q : q; if (a > g_semi_max) g_semi_max = a; }
+            }
+        }
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64_53(hxf::lift(v[i], m)) == ref[i], "semi fwd n=%lu loge=%d p=%lu i=%lu", n, loge, p, i);
+}
+
 // the products inside mul_mod / mul_shoup at such a modulus: |h - k p| must stay below 2^53 (exactness of the fma)
 static void test_prime_wide(uint64_t p) {
     hxf::Mod m{(double)p, 1.0 / (double)p};
@@ -541,6 +580,24 @@ int main() {
         std::printf("strict folded multiply-accumulate (%d primes): max |acc| / p = %.3f (bound 0.9), largest intermediate 2^%.3f (limit 2^53)\n",
                     n_strict, g_fold_strict_max, log2(g_fold_strict_inner));
         CHECK(g_fold_strict_inner < 9007199254740992.0, "strict mac_fold intermediate");
+    }
+    // semi-strict forward schedule: the largest 52-bit primes, SURVEY 8d's 2^52 + 393217 (inside SEMI_MAX_MODULUS), a mid-range strict
+    // prime; every geometry the kernels use (16 or 32 coefficients per thread)
+    {
+        std::vector<uint64_t> sp;
+        for (uint64_t p : primes) if ((double)p > hxf::LAZY_MAX_MODULUS) sp.push_back(p);
+        sp.push_back(4503599627763713ull);
+        for (uint64_t v = (3ull << 50) + 1; sp.size() < 6; v += 32768) if (orc_is_prime(v)) sp.push_back(v);      // ~2^51.58
+        for (uint64_t p : sp) {
+            CHECK((double)p <= hxf::SEMI_MAX_MODULUS && (double)p > hxf::LAZY_MAX_MODULUS, "semi prime %lu", p);
+            for (int adv = 0; adv < 2; ++adv) {
+                test_semi(16384, 4, p, adv); test_semi(16384, 5, p, adv); test_semi(1024, 4, p, adv); test_semi(8192, 5, p, adv);
+                test_semi(4096, 4, p, adv); test_semi(2048, 4, p, adv);
+            }
+        }
+        std::printf("semi-strict forward schedule (%d primes): max |x| after a stage = 2^%.3f, largest intermediate 2^%.3f (limit 2^53)\n",
+                    (int)sp.size(), log2(g_semi_max), log2(g_semi_inner));
+        CHECK(g_semi_inner < 9007199254740992.0 && g_semi_max < 9007199254740992.0, "semi-strict bound exceeded");
     }
     // strict kernels above 2^52 (standalone _NTT / _INTT only): SURVEY 8d's prime and the largest admissible one = 1 mod 2^15
     {
