@@ -690,7 +690,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const u32 last = i == L - 1 ? L - 2 : L - 1;                  // the last d != i
         // rounds d != i except the last: acc += NTT(c_d mod q_i) . key[d][i]
 #if KX_DL_SELECT
-        // (one loop over ALL d != i; the last round's multiply-accumulate picks the t_i addressing at run time)
+        // (one loop over ALL d != i; the last round's multiply-accumulate brings in the raw t_i words in A order like any other input --
+        // only the pointer differs -- and one LDS re-deal takes them to the B positions the accumulators are in)
 #pragma unroll 1
         for (u32 it = first; it < L;) {
             int tid = threadIdx.x;
@@ -709,9 +710,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
             const double* k0 = key_row<G>(a, it, i);
             WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);
             KX_STAMP(4 * it + 2);
-            const bool lastround = it == last;
-            mac_keys<G, LAZYFOLD, 2>(acc0, acc1, v, k0, lastround ? (const double*)ti : round_src(nit), tid, m, lastround);
+            mac_keys<G, FOLD>(acc0, acc1, v, k0, nit < L ? round_src(nit) : (const double*)ti, tid, m);
             it = nit;
+        }
+        {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            redeal_x<G, false, true>(v, ldsx, tid, [](int r, int t) { return G::idxA(r, t); }, [](int r, int t) { return G::idxB(r, t); });
         }
 #else
 #pragma unroll 1
