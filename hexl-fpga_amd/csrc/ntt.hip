@@ -20,6 +20,9 @@
 #ifndef HX_IFWD_PRIO
 #define HX_IFWD_PRIO 1222
 #endif
+#ifndef HX_NTT_NO_SLOW
+#define HX_NTT_NO_SLOW 0   // 1 = TIMING ONLY (wrong results for out-of-range words / bad tables): the persistent fast-path kernels without their
+#endif                     // out-of-line integer fallbacks -- what the presence of those calls costs the FP64 path
 #ifndef HX_IFWD_PERSIST_DEFAULT
 #define HX_IFWD_PERSIST_DEFAULT 0
 #endif
@@ -267,11 +270,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         // the same for every polynomial and wave-uniform -- the whole batch goes straight through the integer butterflies.
         // (Rounds 2-3 ran the FP64 transform on every polynomial first and only then fell back: the transform twice.)
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
+#if !HX_NTT_NO_SLOW
 #pragma unroll 1
         for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
             slow_fwd<LOGN, LOGE>(x + size_t(p) * G::N, lds, roots, precon, q);
             __syncthreads();
         }
+#endif
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
@@ -304,8 +309,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
         } else {
+#if !HX_NTT_NO_SLOW
             slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
             __syncthreads();
+#endif
         }
     }
 }
@@ -323,11 +330,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     const Mod m{(double)q, 1.0 / (double)q};
     if (*violations != 0) {                                                     // see k_ntt_fwd_p
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
+#if !HX_NTT_NO_SLOW
 #pragma unroll 1
         for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
             slow_inv<LOGN, LOGE>(x + size_t(p) * G::N, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
             __syncthreads();
         }
+#endif
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
@@ -365,8 +374,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
         } else {
+#if !HX_NTT_NO_SLOW
             slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
             __syncthreads();
+#endif
         }
     }
 }
