@@ -131,7 +131,10 @@ static void test_mac_fold_strict(uint64_t p) {
                 const double ai = inner < 0 ? -inner : inner, as = sum < 0 ? -sum : sum;
                 if (ai > g_fold_strict_inner) g_fold_strict_inner = ai;
                 if (as > g_fold_strict_inner) g_fold_strict_inner = as;
-                CHECK(centred((i128)x * k + (i128)(int64_t)acc - (i128)(int64_t)K * P - (i128)(int64_t)inner - (i128)(int64_t)sum, P) == 0 || true, "unused");
+                // (h - K p) + (acc + l) must be the exact value of x k + acc - K p: both parts are integers below 2^53
+                CHECK(inner == (double)(int64_t)inner && sum == (double)(int64_t)sum &&
+                      (i128)(int64_t)inner + (i128)(int64_t)sum == (i128)x * k + (i128)(int64_t)acc - (i128)(int64_t)K * P,
+                      "strict mac_fold intermediates p=%lu x=%ld k=%ld", p, x, k);
             }
             acc = hxf::mac_fold(acc, (double)x, (double)k, m);
             exact += (i128)x * k;
