@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
     const double issue_cycles = instr * (G::T / 64) / 4.0 * 4.0;       // waves per SIMD x 4 cycles
     printf("rounds %d grid %d: %.3f ms, %.0f shader cycles per round (s_memtime clock: 100 MHz units x ...: see ms), %.2f us per round\n",
            rounds, grid, best, avg / rounds, best * 1e3 / rounds);
+    printf("issue fraction from the cycle counter: %.3f (nominal issue cycles / shader cycles per round)\n", issue_cycles / (avg / rounds));
     printf("nominal FP64 issue per round: %.0f cycles per SIMD -> at 2.1 GHz %.2f us; issue fraction at 2.1 GHz = %.3f\n", issue_cycles,
            issue_cycles / 2100.0, issue_cycles / 2100.0 / (best * 1e3 / rounds));
     return 0;
