@@ -373,6 +373,26 @@ def pmc_inrun(L, cus, timeout_s=90):
         return None, f"{type(e).__name__}: {str(e)[:300]}"
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_gpus, argv=None):
+    """Re-run this script as `n_gpus` ranks under torch.distributed.run on this node (rendezvous on 127.0.0.1, a free port) and
+    return the launcher's exit status; the ranks see WORLD_SIZE and take the normal path. Rank 0's JSON line is the only stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()),
+           *(sys.argv[1:] if argv is None else argv)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")                # torch.distributed.run would set (and warn about) it anyway
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,6 +409,15 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic / roofline.alu from profiles/*_latest.json instead of in-run PMC passes")
     a = ap.parse_args()
     assert not (a.batch and a.total_batch), "--batch (per GPU, weak) and --total-batch (all GPUs, strong) exclude each other"
+    assert a.gpus >= 1, "--gpus must be positive"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one process per GPU, the reference's DevicePool of
+        # NUM_DEV runners, host/src/fpga.cpp:1646-1673) instead of silently measuring one GPU
+        sys.exit(self_launch(a.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU "
+                 f"(python bench.py --gpus {a.gpus} does that itself) -- refusing to report a rate for the wrong number of GPUs")
 
     import torch
     import torch.distributed as dist

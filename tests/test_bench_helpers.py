@@ -67,3 +67,38 @@ def test_short_kernels_do_not_get_their_own_clock():
     sp = d["kernels"]["k_ksx_special<14, 4, 3, true>"]
     assert abs(d["shader_clock_ghz"] - 2.1) < 1e-9 and abs(sp["shader_clock_ghz"] - 2.1) < 1e-9 and sp["shader_clock_ghz_raw"] > 3.0
     assert abs(sp["fp64_issue_frac"] - 5.58e7 * 4 / 1024 / 2.1e3 / 165.5) < 1e-9 and 0.6 < sp["fp64_issue_frac"] < 0.65
+
+
+def test_gpus_flag_is_never_silently_ignored(monkeypatch):
+    """`--gpus N` means N ranks: without a launcher bench.py becomes one (torch.distributed.run, 127.0.0.1, one process per GPU --
+    the reference's DevicePool of NUM_DEV runners, host/src/fpga.cpp:1646-1673); under a launcher with another WORLD_SIZE it refuses."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        class R: returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    try:
+        bench.main()
+        raise AssertionError("main() must exit with the launcher's status")
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [str(ROOT / "bench.py"), "--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher whose world differs from --gpus: refuse before touching a GPU
+    for world, gpus in (("1", "2"), ("2", "1"), ("8", "4")):
+        monkeypatch.setenv("WORLD_SIZE", world)
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", gpus])
+        try:
+            bench.main()
+            raise AssertionError("must refuse")
+        except SystemExit as e:
+            assert "WORLD_SIZE" in str(e.code) and "refusing" in str(e.code)

@@ -47,3 +47,26 @@ def test_two_ranks_weak_mode():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["verified_vs_oracle"] is True
     assert d["config"]["global_batch"] == 1024 and d["config"]["batch_per_gpu"] == 512
     assert abs(d["value"] - 2 * 512 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+def test_gpus_flag_alone_launches_the_ranks():
+    """`python bench.py --gpus 2` with NO external launcher (the shape of the driver's N = 1 command with another N): bench.py
+    launches its own ranks (round 4: the flag was parsed and ignored, a bare `--gpus 8` measured one GPU and printed n_gpus 1)."""
+    env = dict(os.environ, HEXL_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--total-batch", "2048"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["verified_vs_oracle"] is True
+    assert d["config"]["batch_per_gpu"] == 1024
+    ntt = d["extra"]["ntt_N16384_batch1024"]
+    assert ntt["fwd"]["n_gpus"] == 2 and ntt["fwd"]["ntt_per_s_all_ranks"] > 0
+    # and a launcher whose world disagrees with the flag is refused, not mis-reported
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=str(ROOT))
+    assert bad.returncode != 0 and "refusing" in bad.stderr
