@@ -236,6 +236,64 @@ def cxx_api_end_to_end(L, timeout_s=120):
     return out
 
 
+SEAL_CHAIN_BITS = (52, 30, 30, 40, 27, 27, 27)
+
+
+def seal_chain_rows(hx, ctx, orc_mod, dev, batch=2048, lone_launches=2000):
+    """The reference's own SEAL workload (experimental/bridge-seal/tests/seal_test.sh:20: N = 16384, CoeffModulus::Create(16384,
+    {52, 30, 30, 40, 27, 27, 27}), relinearize at 6 decomposition limbs, rotate after the rescale at 5 of 7 key moduli) on the device:
+    keyswitch/s at `batch` and microseconds per LONE keyswitch (the bridge calls at worksize 1), each with per-limb arithmetic tiers
+    (limb 0 strict, the others at reduction period 12: round 5) and with the plan-wide tier of rounds 1-4 (HEXL_KS_PER_LIMB=0: the
+    52-bit limb puts all seven on the strict kernels). Device-resident; the host-pointer rate is extra.cxx_api_end_to_end's."""
+    import torch
+    from ks_util import KsCase, seal_chain
+    moduli = seal_chain(orc_mod, 7, N)
+    rows = {"moduli": [int(q) for q in moduli], "batch": batch}
+    for name, Lx in (("relinearize_L6_K7", 6), ("rotate_L5_K7", 5)):
+        row = {}
+        for label, per_limb in (("per_limb_tiers", "1"), ("plan_wide_tier", "0")):
+            os.environ["HEXL_KS_PER_LIMB"] = per_limb                     # read when the plan is created
+            try:
+                cs = KsCase(orc_mod, N, Lx, 7, seed=41, moduli=moduli)
+                pl = hx.KeySwitchPlan(ctx, N, Lx, 7, 7, 2, cs.moduli, cs.modswitch)
+            finally:
+                os.environ.pop("HEXL_KS_PER_LIMB", None)
+            pl.set_keys(cs.keys)
+            tiers, mixed = pl.tiers()
+            tt, rr = cs.inputs(orc_mod, 0)                                # parity of this very plan before it is timed
+            d_t1, d_r1 = hx.as_i64(tt).to(dev), hx.as_i64(rr).to(dev)
+            pl.keyswitch(d_r1, d_t1, 1)
+            torch.cuda.synchronize()
+            ok = bool(np.array_equal(hx.to_u64(d_r1), cs.expected(orc_mod, tt, rr)))
+            tx, rx = device_inputs(hx, orc_mod, cs, batch, dev)
+            pl.keyswitch(rx, tx, batch)
+            torch.cuda.synchronize()
+            probe = hx.to_u64(rx[batch - 1]).copy()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            for _ in range(5):
+                pl.keyswitch(rx, tx, batch)
+            f1.record()
+            torch.cuda.synchronize()
+            ms = f0.elapsed_time(f1) / 5
+            for _ in range(50):
+                pl.keyswitch(d_r1, d_t1, 1)
+            torch.cuda.synchronize()
+            f0.record()
+            for _ in range(lone_launches):
+                pl.keyswitch(d_r1, d_t1, 1)
+            f1.record()
+            torch.cuda.synchronize()
+            row[label] = {"tiers": tiers[:Lx] + tiers[6:], "mixed": mixed, "verified_vs_oracle": ok,
+                          "keyswitches_per_s": batch / (ms * 1e-3), "lone_keyswitch_us": f0.elapsed_time(f1) * 1e3 / lone_launches}
+            del probe
+            pl.close()
+        row["speedup_batch"] = row["per_limb_tiers"]["keyswitches_per_s"] / row["plan_wide_tier"]["keyswitches_per_s"]
+        row["speedup_lone"] = row["plan_wide_tier"]["lone_keyswitch_us"] / row["per_limb_tiers"]["lone_keyswitch_us"]
+        rows[name] = row
+    return rows
+
+
 class PowerSampler:
     """Board power and shader clock from the amdgpu hwmon files of the benchmarked GPU, sampled every 50 ms on a thread while
     the timed region runs. Every kernel family of this library runs the board AT its power cap (1378-1400 W of
@@ -667,6 +725,8 @@ def main():
                     v -= 2 * N
                 return out_
             extra["keyswitch_16384_L%d_largest_52bit_primes_strict_kernels" % L] = other_shape(L, L + 1, largest_52bit_primes(L + 1))
+            # the reference's own SEAL workload (bridge-seal's prime chain 52,30,30,40,27,27,27): per-limb tiers against the plan-wide tier
+            extra["keyswitch_seal_chain_52_30_30_40_27_27_27"] = seal_chain_rows(hx, ctx, orc_mod, dev, batch=min(mine, 2048))
             # the headline shape on the 64-bit INTEGER kernels (59-bit primes: beyond the reference's < 2^52 envelope)
             extra["keyswitch_16384_L%d_59bit_primes_integer_kernels" % L] = other_shape(L, L + 1, orc_mod.primes(L + 1, 59, N))
         out["extra"] = extra

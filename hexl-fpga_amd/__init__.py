@@ -50,6 +50,7 @@ C_ABI = {
     "hexl_ks_set_keys": [_vp, ctypes.POINTER(_vp)],
     "hexl_keyswitch": [_vp, _vp, _vp, _sz],
     "hexl_ks_range_check": [_vp],
+    "hexl_ks_plan_tiers": [_vp, ctypes.POINTER(_i)],
     "hexl_multiply_relinearize": [_vp, _vp, _vp, _vp, _sz],
     "hexl_ks_scratch_bytes": [_vp, _sz],
     "hexl_ntt_fwd_host": [_vp, ctypes.POINTER(_vp), _sz, _vp, _vp, _u64, _u64],
@@ -200,6 +201,14 @@ class KeySwitchPlan:
         if rc not in (0, 1):                                       # 1 = HEXL_W_RANGE
             _check(rc, "hexl_ks_range_check")
         return rc == 0
+
+    def tiers(self):
+        """(per-limb forward reduction periods [K] -- 0 = strict, -1 = integer kernels --, True when the limbs in use differ)"""
+        out = (_i * self.K)()
+        rc = lib().hexl_ks_plan_tiers(self.h, out)
+        if rc not in (0, 1):
+            _check(rc, "hexl_ks_plan_tiers")
+        return list(out), rc == 1
 
     def multiply_relinearize(self, out, a, b, batch: int):
         """out[batch][2][L][n] = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), one fused pass (N = 1024 ... 16384)"""

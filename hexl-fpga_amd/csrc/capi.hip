@@ -219,8 +219,17 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         const char* sk = getenv("HEXL_KSX_SKIP");                   // 0: keep the range reductions (tests)
         p->x_skip = p->f64_lazy && qmax <= hxf::LAZY_SKIP_MAX_RATIO * qmin && !(sk && atoi(sk) == 0);
         const char* e = getenv("HEXL_KS_PERIOD");               // testing: force a SHORTER period (always valid)
-        if (e && p->f64_lazy && atoi(e) > 0 && atoi(e) <= p->f64_lazy && (atoi(e) == 3 || atoi(e) == 6 || atoi(e) == 12))
-            p->f64_lazy = atoi(e);
+        const int cap = (e && (atoi(e) == 3 || atoi(e) == 6 || atoi(e) == 12)) ? atoi(e) : 12;
+        if (p->f64_lazy > cap) p->f64_lazy = cap;
+        // per-limb tiers: limb i's transforms run modulo q_i alone (hexl_internal.hpp); HEXL_KS_PER_LIMB=0: the plan-wide tier for all
+        const char* pl = getenv("HEXL_KS_PER_LIMB");
+        const bool per_limb = !(pl && atoi(pl) == 0);
+        for (u64 i = 0; i < K; ++i) {
+            int t = per_limb ? hxf::lazy_period_for((double)h_moduli[i]) : p->f64_lazy;
+            if (t > cap) t = cap;
+            p->tier[i] = (unsigned char)t;
+            if ((i < L || i == K - 1) && t != p->f64_lazy) p->mixed = true;
+        }
     }
     if (f64_ok) {
         std::vector<KsModF64> fm(K);
@@ -355,6 +364,12 @@ extern "C" int hexl_keyswitch(hexl_ks_plan* p, uint64_t* d_result, const uint64_
     if (!p || !d_result || !d_t_target) return HEXL_E_BADARG;
     HX_CHECK(hipSetDevice(p->ctx->device));
     return hx_launch_keyswitch(p, d_result, d_t_target, batch, 7, nullptr);
+}
+
+extern "C" int hexl_ks_plan_tiers(const hexl_ks_plan* p, int* tiers) {
+    if (!p || !tiers) return HEXL_E_BADARG;
+    for (u32 i = 0; i < p->K; ++i) tiers[i] = p->use_f64 ? (int)p->tier[i] : -1;
+    return p->use_f64 && p->mixed ? 1 : 0;
 }
 
 extern "C" int hexl_ks_range_check(hexl_ks_plan* p) {

@@ -104,7 +104,14 @@ struct hexl_ks_plan {
     bool have_keys = false;
     // FP64 path (all moduli < 2^52): same tables / keys as centred doubles
     bool use_f64 = false;
-    int f64_lazy = 0;                 // forward reduction period of the lazy kernels (3, 6, 12 by modulus size); 0 = strict
+    int f64_lazy = 0;                 // forward reduction period of the lazy kernels (3, 6, 12 by modulus size); 0 = strict -- the tier every
+                                      // modulus of the plan admits (chosen from the LARGEST one)
+    // Per-limb arithmetic tier (round 5): a transform runs modulo ONE q_i, so its reduction period depends on that modulus alone, as
+    // every NTT engine of the reference runs on its own modulus (device/keyswitch/ntt_core.hpp:285-291, ntt1.hpp:107-128).
+    // tier[i] = forward reduction period for limb i (0 = strict); `mixed` = some limb the plan uses admits a longer period than f64_lazy
+    // (e.g. bridge-seal's chain 52,30,30,40,27,27,27: one strict limb, six at period 12). HEXL_KS_PER_LIMB=0 keeps the plan-wide tier.
+    unsigned char tier[16] = {};
+    bool mixed = false;
     u32 f64_loge = 4;                 // elements-per-thread exponent of the FP64 kernels (fixes the keys' B order)
     KsModF64* d_mods_f64 = nullptr;   // [K]
     double* d_tables_f64 = nullptr;   // [K][4][n]

@@ -35,6 +35,7 @@ struct KsArgsF {
     u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
     u32 overwrite;           // 1: `result` is written, not accumulated into (the host-pointer path: the HOST adds, fpga.cpp:441-475)
     u32 skip;                // latency path: moduli of one size (hexl_ks_plan::x_skip) -> s' enters the mod-down transform un-reduced
+    unsigned long long tiermap;   // kernels built with LAZY = -1 (plans of mixed tiers): nibble i = reduction period of limb i
 };
 
 __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswitch.hip: XCD-contiguous work ranges
@@ -67,7 +68,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) ud[r * G::T + tid] = v[r];
     }
-    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    with_tier<LAZY, false>(a.tiermap, d, [&](auto T) {             // (an inverse transform has two forms: strict and lazy)
+        WgNttF64<LOGN, LOGE, decltype(T)::value>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    });
     double* dst = a.c + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[G::idxA(r, tid)] = hxf::lift(v[r], md.m);
@@ -80,7 +83,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (batch 32 at N = 16384: -5 %)
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -101,7 +103,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     const double* tb = a.tables + size_t(i) * 4 * G::N;
     // no final range reduction (LAZY): |u| <= 2.14p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
     // |result| < p); tests/cpp/f64_selftest.cpp replays exactly this chain against 128-bit integers
-    W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
+    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+        using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (batch 32 at N = 16384: -5 %)
+        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
+    });
 #pragma unroll
     for (int r = 0; r < G::E; ++r) dst[r * G::T + tid] = v[r];
 }
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
 // u is kept in the forward transform's register order ("B order", fully coalesced).
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
+    static_assert(LAZY >= 0, "one schedule for all L + 1 transforms of the workgroup: plans of mixed tiers run k_ksf_intt + k_ksf_ntt_up");
     using G = Geom<LOGN, LOGE>;
     // FPRIO 1222: this workgroup runs L transforms back to back -- the pass in front of the cross-wave barrier at the lower wave
     // priority (ntt_core_f64.hpp hx_fwd_prio): N = 32768, L = 3, batch 2048: 143.5 k -> 163.5 k keyswitch/s (+14 %)
@@ -222,7 +228,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
     double v[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = __builtin_nontemporal_load(&src[r * G::T + tid]);
-    WgNttF64<LOGN, LOGE, LAZY>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
+    with_tier<LAZY, false>(a.tiermap, i, [&](auto T) {
+        WgNttF64<LOGN, LOGE, decltype(T)::value>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, m, md.sc);
+    });
     double* dst = a.s + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r)                                // intt2_redu.hpp:25,43
@@ -233,7 +241,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt_sp(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (N = 16384: +-0)
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -254,16 +261,19 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     // prod is requested right after the cross-wave re-deal and lands during the remaining passes; result is
     // requested first thing in the epilogue and lands during the (prod - w) * msf multiplications
     double pv[G::E];
-    if constexpr (G::HALF_ONLY) {                                  // N = 32768: no registers to hold prod during the transform
-        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
-    } else {
-        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {    // |w| <= 2.14p: |prod - w| <= 2.64p below
+    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+        using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (N = 16384: +-0)
+        if constexpr (G::HALF_ONLY) {                              // N = 32768: no registers to hold prod during the transform
+            W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
 #pragma unroll
             for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
-        });
-    }
+        } else {
+            W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {    // |w| <= 2.14p: |prod - w| <= 2.64p below
+#pragma unroll
+                for (int r = 0; r < G::E; ++r) pv[r] = (pk + r * G::T)[u32(tid)];
+            });
+        }
+    });
     const u32 tB = u32(G::idxB(0, tid));
     if (!G::HALF_ONLY && a.overwrite) {                           // host-pointer path: the output itself, canonical; the HOST adds
 #pragma unroll
@@ -327,7 +337,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_intt(KsArgsF a) {
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);   // canonical words as they are
     hxf::report_range(bad, a.range_flag);
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    with_tier<LAZY, false>(a.tiermap, d, [&](auto T) {
+        WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, true>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+    });
     double* dst = a.c + size_t(item) * G::N;
 #pragma unroll
     for (int r = 0; r < G::E; ++r) (dst + G::idxA(r, 0))[u32(tid)] = hxf::lift(v[r], md.m);
@@ -336,7 +348,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_intt(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -366,7 +377,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_up(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce((cd + G::idxA(r, 0))[u32(tid)], m);   // c_d mod q_i (intt1_redu.hpp:36-42)
         const double* tb = a.tables + size_t(i) * 4 * G::N;
-        W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, request_keys);          // |u| <= 2.14p; keys behind the cross-wave re-deal
+        with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {                                // |u| <= 2.14p; keys behind the cross-wave re-deal
+            WgNttF64<LOGN, LOGE, decltype(T)::value>::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, request_keys);
+        });
     }
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.prod) + size_t(b) * 2 * (L + 1) * G::N;
     unsigned long long* p0 = acc + size_t(0 * (L + 1) + slot) * G::N;
@@ -384,8 +397,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_up(KsArgsF a) {
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY>;
-    using WI = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x;
     const u32 L = a.L;
@@ -403,7 +414,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52(fold_below_q<4>((psp + r * G::T)[u32(tid)], qsp));
         const double* ts = a.tables + size_t(a.K - 1) * 4 * G::N;
-        WI::template inverse<true>(v, ldsd, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
+        with_tier<LAZY, false>(a.tiermap, a.K - 1, [&](auto T) {
+            WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, true>::template inverse<true>(v, ldsd, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
+        });
         // y = s' - floor(q_sp/2), the exact centred remainder (keyswitch_x.hip ksx_special_down; intt2_redu.hpp:25-51), A order
 #pragma unroll
         for (int r = 0; r < G::E; ++r) {
@@ -417,9 +430,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
     }
     const double* tb = a.tables + size_t(i) * 4 * G::N;
     u64 praw[G::E];
-    W::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {     // |w| <= 2.14p
+    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+        WgNttF64<LOGN, LOGE, decltype(T)::value>::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {     // |w| <= 2.14p
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) praw[r] = (pi + r * G::T)[u32(tid)];
+            for (int r = 0; r < G::E; ++r) praw[r] = (pi + r * G::T)[u32(tid)];
+        });
     });
     const u64 qi = (u64)m.p;
     u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * G::N;
@@ -458,7 +473,8 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     using G = Geom<LOGN, LOGE>;
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
-            int rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_USED);
+            int rc = 0;
+            if constexpr (LAZY >= 0) rc = set_lds(k_ksf_up<LOGN, LOGE, LAZY>, G::LDS_USED);
             if (!rc) rc = set_lds(k_ksf_intt<LOGN, LOGE, LAZY>, G::LDS_USED);
             if (!rc) rc = set_lds(k_ksf_ntt_up<LOGN, LOGE, LAZY>, G::LDS_USED);
             if (!rc) rc = set_lds(k_ksf_intt_sp<LOGN, LOGE, LAZY>, G::LDS_USED);
@@ -498,12 +514,12 @@ static int run_chunk_f64(hexl_ks_plan* p, const KsArgsF& a, int stage_mask, hipE
     // (the same fusion of steps 4-7 -- s' in registers, L mod-down transforms per workgroup -- measured 8 % slower
     // than the two kernels below: its epilogue loads cannot be requested early, tools/experiments/fused_down.patch)
     static const int fuse = [] { const char* e = getenv("HEXL_KS_FUSE"); return e ? atoi(e) : 1; }();
-    const bool fused_up = (fuse & 1) && nb * L >= 2 * cus && !G::HALF_ONLY;   // N = 32768: 64 VGPRs of data already
+    const bool fused_up = LAZY >= 0 && (fuse & 1) && nb * L >= 2 * cus && !G::HALF_ONLY;   // N = 32768: 64 VGPRs of data already
     // timing stages: 1 = steps 1-2 (inverse + mod-up transforms), 2 = steps 3-4, 4 = steps 5-7
     if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     if (stage_mask & 1) {
         if (fused_up) {
-            hipLaunchKernelGGL((k_ksf_up<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_USED, st, a);
+            if constexpr (LAZY >= 0) hipLaunchKernelGGL((k_ksf_up<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_USED, st, a);
         } else {
             hipLaunchKernelGGL((k_ksf_intt<LOGN, LOGE, LAZY>), dim3(nb * L), dim3(G::T), G::LDS_USED, st, a);
             hipLaunchKernelGGL((k_ksf_ntt_up<LOGN, LOGE, LAZY>), dim3(nb * L * L), dim3(G::T), G::LDS_USED, st, a);
@@ -540,6 +556,19 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.range_flag = p->d_flag;
     a.overwrite = p->overwrite_result ? 1u : 0u;
     a.skip = p->x_skip ? 1u : 0u;
+    a.tiermap = 0;
+    for (u32 i = 0; i < p->K; ++i) a.tiermap |= (unsigned long long)(p->tier[i] & 15u) << (4 * i);
+    if (p->mixed) {                                               // limbs of different tiers: the schedule is looked up per transform
+        switch (p->logn) {
+            case 10: return run_chunk_f64<10, 4, -1>(p, a, stage_mask, ev);
+            case 11: return run_chunk_f64<11, 5, -1>(p, a, stage_mask, ev);
+            case 12: return run_chunk_f64<12, 5, -1>(p, a, stage_mask, ev);
+            case 13: return run_chunk_f64<13, 5, -1>(p, a, stage_mask, ev);
+            case 14: return run_chunk_f64<14, 4, -1>(p, a, stage_mask, ev);
+            case 15: return run_chunk_f64<15, 5, -1>(p, a, stage_mask, ev);
+            default: return HEXL_E_BADARG;
+        }
+    }
     // LAZY template argument = forward reduction period (f64_arith.hpp): 3 when every modulus <= 2^51(1+2^-7), 6 / 12
     // for moduli <= 2^50 / 2^49 (N = 16384 only; the smaller transforms keep 3), 0 = strict
     if (p->f64_lazy) {

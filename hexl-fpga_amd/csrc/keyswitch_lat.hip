@@ -47,6 +47,7 @@ struct KsArgsQ {
     u32 L, K;
     u32* range_flag;
     u32 overwrite, skip;     // as in keyswitch_f64.hip
+    unsigned long long tiermap;   // kernels built with LAZY = -1 (plans of mixed tiers): nibble i = reduction period of limb i (with_tier)
 };
 
 // A sub-transform workgroup is alone on its compute unit: one wave per SIMD, nobody to cover a dependent FP64 chain's latency but
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_intt(KsArgsQ a) {
     hxf::report_range(bad, a.range_flag);
     a_to_b(v, ldsq, tid);
     const double* tb = a.tables + size_t(d) * 4 * (1 << QLOGN);
-    WgSubNtt<LAZY>::template inv_pass<0>(v, ldsq, tid, q, tb + 2 * (1 << QLOGN), md.m);
+    with_tier<LAZY, false>(a.tiermap, d, [&](auto T) {
+        WgSubNtt<decltype(T)::value>::template inv_pass<0>(v, ldsq, tid, q, tb + 2 * (1 << QLOGN), md.m);
+    });
     double* dst = a.sub + (size_t(b) * L + d) * (1 << QLOGN) + size_t(q) * QM;
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) (dst + GQ::idxA(r, 0))[u32(tid)] = v[r];
@@ -199,16 +202,24 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_up(KsArgsQ a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) sv[r][k] = (sb + size_t(k) * QM + GQ::idxA(r, 0))[u32(tid)];
         request_keys();
+        // the inverse's last two stages run modulo q_d in q_d's tier (strict or lazy: the two forms an inverse butterfly has), the forward
+        // transform modulo q_i in q_i's
+        with_tier<LAZY, false>(a.tiermap, d, [&](auto TD) {
 #pragma unroll
-        for (int r = 0; r < GQ::E; ++r) {
-            double c[4] = {sv[r][0], sv[r][1], sv[r][2], sv[r][3]};
-            inverse_finish<LAZY>(c, tbd + 2 * N, md.m, md.sc);                             // c_d at j, j + n/4, j + n/2, j + 3n/4
+            for (int r = 0; r < GQ::E; ++r) {
+                inverse_finish<decltype(TD)::value>(sv[r], tbd + 2 * N, md.m, md.sc);      // c_d at j, j + n/4, j + n/2, j + 3n/4
 #pragma unroll
-            for (int k = 0; k < 4; ++k) c[k] = hxf::reduce(hxf::lift(c[k], md.m), m);       // canonical, then mod q_i (intt1_redu.hpp:36-42)
-            forward_start<LAZY>(c, tbi, m);
-            v[r] = q == 0 ? c[0] : q == 1 ? c[1] : q == 2 ? c[2] : c[3];
-        }
-        WgSubNtt<LAZY>::template fwd_pass<0>(v, ldsq, tid, q, tbi, m);
+                for (int k = 0; k < 4; ++k) sv[r][k] = hxf::reduce(hxf::lift(sv[r][k], md.m), m);   // canonical, then mod q_i (intt1_redu.hpp:36-42)
+            }
+        });
+        with_tier<LAZY, true>(a.tiermap, i, [&](auto TI) {
+#pragma unroll
+            for (int r = 0; r < GQ::E; ++r) {
+                forward_start<decltype(TI)::value>(sv[r], tbi, m);
+                v[r] = q == 0 ? sv[r][0] : q == 1 ? sv[r][1] : q == 2 ? sv[r][2] : sv[r][3];
+            }
+            WgSubNtt<decltype(TI)::value>::template fwd_pass<0>(v, ldsq, tid, q, tbi, m);
+        });
         b_to_a(v, ldsq, tid);
     }
     unsigned long long* p0 = a.prod + (size_t(b) * 2 * (L + 1) + slot) * N + size_t(q) * QM;
@@ -237,7 +248,9 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_intt_sp(KsArgsQ a) {
     for (int r = 0; r < GQ::E; ++r) v[r] = hxf::to_f64_lt52(fold_below_q4((src + GQ::idxA(r, 0))[u32(tid)], qsp));
     a_to_b(v, ldsq, tid);
     const double* ts = a.tables + size_t(a.K - 1) * 4 * N;
-    WgSubNtt<LAZY>::template inv_pass<0>(v, ldsq, tid, q, ts + 2 * N, msp.m);
+    with_tier<LAZY, false>(a.tiermap, a.K - 1, [&](auto T) {
+        WgSubNtt<decltype(T)::value>::template inv_pass<0>(v, ldsq, tid, q, ts + 2 * N, msp.m);
+    });
     double* dst = a.subsp + (size_t(b) * 2 + k) * N + size_t(q) * QM;
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) (dst + GQ::idxA(r, 0))[u32(tid)] = v[r];
@@ -273,21 +286,27 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
 #pragma unroll
         for (int r = 0; r < GQ::E; ++r) old[r] = (res + GQ::idxA(r, 0))[u32(tid)];
     }
+    with_tier<LAZY, false>(a.tiermap, a.K - 1, [&](auto TS) {          // the special prime's tier, then limb i's
 #pragma unroll
-    for (int r = 0; r < GQ::E; ++r) {
-        double c[4] = {sv[r][0], sv[r][1], sv[r][2], sv[r][3]};
-        inverse_finish<LAZY>(c, ts + 2 * N, msp.m, msp.sc);
+        for (int r = 0; r < GQ::E; ++r) {
+            inverse_finish<decltype(TS)::value>(sv[r], ts + 2 * N, msp.m, msp.sc);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            // y = s' - floor(q_sp/2): the exact centred remainder (keyswitch_x.hip ksx_special_down; intt2_redu.hpp:25-51)
-            const double cc = hxf::lift(c[kk], msp.m);
-            c[kk] = cc > msp.half ? cc - msp.m.p : cc;
-            if (!a.skip) c[kk] = hxf::reduce(c[kk], m);
+            for (int kk = 0; kk < 4; ++kk) {
+                // y = s' - floor(q_sp/2): the exact centred remainder (keyswitch_x.hip ksx_special_down; intt2_redu.hpp:25-51)
+                const double cc = hxf::lift(sv[r][kk], msp.m);
+                sv[r][kk] = cc > msp.half ? cc - msp.m.p : cc;
+                if (!a.skip) sv[r][kk] = hxf::reduce(sv[r][kk], m);
+            }
         }
-        forward_start<LAZY>(c, tb, m);
-        v[r] = q == 0 ? c[0] : q == 1 ? c[1] : q == 2 ? c[2] : c[3];
-    }
-    WgSubNtt<LAZY>::template fwd_pass<0>(v, ldsq, tid, q, tb, m);                      // |w| <= 2.14p
+    });
+    with_tier<LAZY, true>(a.tiermap, i, [&](auto TI) {
+#pragma unroll
+        for (int r = 0; r < GQ::E; ++r) {
+            forward_start<decltype(TI)::value>(sv[r], tb, m);
+            v[r] = q == 0 ? sv[r][0] : q == 1 ? sv[r][1] : q == 2 ? sv[r][2] : sv[r][3];
+        }
+        WgSubNtt<decltype(TI)::value>::template fwd_pass<0>(v, ldsq, tid, q, tb, m);   // |w| <= 2.14p
+    });
     b_to_a(v, ldsq, tid);
     const u64 qi = (u64)m.p;
     hxf::RangeMask bad = 0;
@@ -354,6 +373,9 @@ int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.range_flag = p->d_flag;
     a.overwrite = p->overwrite_result ? 1u : 0u;
     a.skip = p->x_skip ? 1u : 0u;
+    a.tiermap = 0;
+    for (u32 i = 0; i < p->K; ++i) a.tiermap |= (unsigned long long)(p->tier[i] & 15u) << (4 * i);
+    if (p->mixed) return run_lat<-1>(p, a, (u32)nb);              // limbs of different tiers: looked up per transform (with_tier)
     switch (p->f64_lazy) {
         case 12: return run_lat<12>(p, a, (u32)nb);
         case 6:  return run_lat<6>(p, a, (u32)nb);

@@ -126,6 +126,11 @@ struct KsArgsX {
     const u64* t_target;     // [chunk][L][n]
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
+    // the limbs THIS launch works on (k_ksx_intt: d, k_ksx_main: i): limb number j < nsel is nibble j of selmap. A plan whose moduli
+    // share one arithmetic tier launches once with nsel = L and the identity map; a plan of mixed tiers (hexl_ks_plan::mixed) launches
+    // each kernel once per tier with that tier's limbs -- a workgroup transforms modulo ONE q_i, so its reduction period is that limb's
+    u32 nsel;
+    unsigned long long selmap;
     u32* range_flag;         // set to 1 when a t_target / result word is not below its modulus (hexl_ks_range_check)
     u32 key_stride;          // words between key[d][slot] rows: 2 n (profiling builds, alias bit 1: 0)
     u32 alias;               // profiling builds only (KX_ALIASED); 0 in the shipped library
@@ -162,6 +167,8 @@ __device__ __forceinline__ XcdWalk xcd_walk(u32 total) {
     const u32 start = x * q + (x < r ? x : r);
     return XcdWalk{start + j, start + q + (x < r ? 1u : 0u), g};
 }
+
+__device__ __forceinline__ u32 sel_limb(const KsArgsX& a, u32 j) { return u32(a.selmap >> (4 * j)) & 15u; }
 
 // the per-modulus constants of limb i, read through the constant address space (ten doubles: scalar loads)
 __device__ __forceinline__ KsModF64 load_mod_const(const KsModF64* p) {
@@ -363,13 +370,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
     using G = Geom<LOGN, LOGE>;
     using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>;         // inverse without the w/p table
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
-    const XcdWalk wk = xcd_walk(a.nb * a.L);
+    const XcdWalk wk = xcd_walk(a.nb * a.nsel);
     if (wk.pos >= wk.end) return;
     // the next item's words are requested into spare registers behind the last per-lane twiddle request of the current
     // transform (WgNttF64::inverse's `before_uniform` hook; see k_ntt_inv_p): the item loop never waits for its input
     auto src_of = [&](u32 item) -> const u64* {
         if constexpr (FUSED) return nullptr;
-        else return a.t_target + size_t(KX_ALIASED(4, item / a.L) * a.L + item % a.L) * G::N;
+        else return a.t_target + size_t(KX_ALIASED(4, item / a.nsel) * a.L + sel_limb(a, item % a.nsel)) * G::N;
     };
     u64 raw[G::E];
     hxf::RangeMask bad = 0;                                             // a t_target word >= its modulus (FP64 precondition)
@@ -380,17 +387,19 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
         for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
     }
 #pragma unroll 1
-    for (u32 item = wk.pos; item < wk.end; item += wk.step) {     // item = b*L + d
+    for (u32 item = wk.pos; item < wk.end; item += wk.step) {     // item = b*nsel + (number of d among this launch's limbs)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const u32 d = __builtin_amdgcn_readfirstlane(item % a.L);
+        const u32 ib = item / a.nsel;
+        const u32 d = __builtin_amdgcn_readfirstlane(sel_limb(a, item - ib * a.nsel));
+        const u32 row = ib * a.L + d;                                 // b*L + d
         const KsModF64 md = a.mods[d];
         u32 toff = KX_ALIASED(16, d) * 4 * G::N;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         double v[G::E];
         if constexpr (FUSED) {                                    // t_target[d] = a_1[d] . b_1[d]
-            const size_t at = ((size_t(item / a.L) * 2 + 1) * a.L + d) * G::N;
+            const size_t at = ((size_t(ib) * 2 + 1) * a.L + d) * G::N;
             load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, md.m);
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         } else if constexpr (G::KL <= 2) {
@@ -407,10 +416,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
             };
             W::template inverse<false, decltype(request_next), (KX_IPRE != 0)>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, request_next);
         } else {
-            load_natural_to_B<G>(v, a.t_target + size_t(item) * G::N, ldsx, tid, md.m, bad);
+            load_natural_to_B<G>(v, a.t_target + size_t(row) * G::N, ldsx, tid, md.m, bad);
             W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
         }
-        double* cd = a.c + size_t(item) * G::N;
+        double* cd = a.c + size_t(row) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (cd + G::idxA(r, 0))[u32(tid)] = hxf::lift(v[r], md.m);
     }
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler
     // hoists out of the item loop costs more registers (34 spilled against 10) than the dispatch gaps cost time
 #if KX_MAIN_PERSIST
-    const XcdWalk wk = xcd_walk(a.nb * L);
+    const XcdWalk wk = xcd_walk(a.nb * a.nsel);
 #pragma unroll 1
     for (u32 item_v = wk.pos; item_v < wk.end; item_v += wk.step)
 #else
@@ -654,10 +663,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
 #if KX_SLOT_MAJOR
     // SLOT-major, XCD-contiguous: an XCD works on one or two limbs at a time, whose keys (2 L n words per limb) then
     // stay in its L2; c_d and s' of one instance are fetched by up to L XCDs (the Infinity Cache absorbs that)
-    const u32 i = item / a.nb, b = item - i * a.nb;
+    const u32 i = sel_limb(a, item / a.nb), b = item % a.nb;
 #else
-    // instance-major, XCD-contiguous: the L workgroups that read the same c_d and s' run side by side on one XCD
-    const u32 b = item / L, i = item - b * L;
+    // instance-major, XCD-contiguous: the workgroups (one per limb of this launch) that read the same c_d and s' run side by side on one XCD
+    const u32 b = item / a.nsel, i = sel_limb(a, item - b * a.nsel);
 #endif
     // (through the constant address space: inside an item loop that also stores to global memory a plain read of these
     // wave-uniform constants becomes a VECTOR load, and p, 1/p, msf ... then occupy vector registers the accumulators need)
@@ -868,8 +877,10 @@ static int set_lds_x(K kern, size_t bytes) {
     return 0;
 }
 
+// one kernel of the pipeline for the limbs `a` selects: stage 1 = k_ksx_intt (step 1), 2 = k_ksx_special (steps 2-4, special slot),
+// 4 = k_ksx_main (steps 2-3 and 5-7 of the decomposition slots)
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
-static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
+static int launch_stage_x(hexl_ks_plan* p, const KsArgsX& a, int stage) {
     using G = Geom<LOGN, LOGE>;
     // the d == i term as the last multiply-accumulate of the mod-up (k_ksx_main<..., DL>): N = 16384 only (measured there), L >= 2
     constexpr bool CAN_DL = KX_DIAG_LATE && !FUSED && LOGN == 14 && LOGE == 4;
@@ -883,8 +894,6 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
         }))
         return rc0;
     hipStream_t st = p->cur;
-    // timing stages: 1 = step 1 (inverse transforms), 2 = special slot (steps 2-4), 4 = decomposition slots (steps 2-3, 5-7)
-    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
     // persistent grids: 8 x g workgroups, g = workgroups per XCD = one per CU unless there are fewer items
     // (HEXL_KSX_PERSIST=0: one workgroup per item)
     static const int persist = [] { const char* e = getenv("HEXL_KSX_PERSIST"); return e ? atoi(e) : 1; }();
@@ -894,19 +903,78 @@ static int run_chunk_x(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEve
         const u32 per_xcd = (items + 7) / 8, slots = (((u32)p->ctx->num_cu + 7) / 8) * wg_per_cu;
         return dim3(8 * (persist && per_xcd > slots ? slots : per_xcd));
     };
-    if (stage_mask & 1)
-        hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY, FUSED>), grid_for(a.nb * a.L), dim3(G::T), G::LDS_USED, st, a);
-    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
-    if (stage_mask & 2)
+    if (stage == 1)
+        hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY, FUSED>), grid_for(a.nb * a.nsel), dim3(G::T), G::LDS_USED, st, a);
+    if (stage == 2)
         hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY, SKIP>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
-    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
-    if (stage_mask & 4) {
-        const dim3 grid = KX_MAIN_PERSIST ? grid_for(a.nb * a.L) : dim3(a.nb * a.L);
+    if (stage == 4) {
+        const dim3 grid = KX_MAIN_PERSIST ? grid_for(a.nb * a.nsel) : dim3(a.nb * a.nsel);
         bool dl = false;
         if constexpr (CAN_DL) dl = a.L >= 2 && diag_late_enabled();
         if constexpr (CAN_DL) if (dl) hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP, true>), grid, dim3(G::T), G::LDS_USED, st, a);
         if (!dl) hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>), grid, dim3(G::T), G::LDS_USED, st, a);
     }
+    return 0;
+}
+
+// the kernel variant of a (tier, SKIP) pair. N = 16384 has all four reduction periods; the smaller rings keep 0 / 3 (a shorter period
+// is always valid: fewer kernel variants), and so does the fused multiply + relinearize
+template <int LOGN, int LOGE, bool FUSED>
+static int launch_stage_tier(hexl_ks_plan* p, const KsArgsX& a, int stage, int tier, bool skip) {
+    if constexpr (LOGN == 14 && LOGE == 4 && !FUSED) {
+        switch (tier * 2 + (skip && tier ? 1 : 0)) {
+            case 25: return launch_stage_x<14, 4, 12, false, true>(p, a, stage);
+            case 24: return launch_stage_x<14, 4, 12>(p, a, stage);
+            case 13: return launch_stage_x<14, 4, 6, false, true>(p, a, stage);
+            case 12: return launch_stage_x<14, 4, 6>(p, a, stage);
+            case 7:  return launch_stage_x<14, 4, 3, false, true>(p, a, stage);
+            case 6:  return launch_stage_x<14, 4, 3>(p, a, stage);
+            default: return launch_stage_x<14, 4, 0>(p, a, stage);
+        }
+    } else if constexpr (LOGE == 5) {                              // 32 coefficients x 512 threads: measured slower, kept for study
+        return tier ? launch_stage_x<LOGN, 5, 3, FUSED>(p, a, stage) : launch_stage_x<LOGN, 5, 0, FUSED>(p, a, stage);
+    } else {
+        if (!tier) return launch_stage_x<LOGN, LOGE, 0, FUSED>(p, a, stage);
+        return skip ? launch_stage_x<LOGN, LOGE, 3, FUSED, true>(p, a, stage) : launch_stage_x<LOGN, LOGE, 3, FUSED>(p, a, stage);
+    }
+}
+
+// One chunk. Plans of ONE tier: three launches, every limb in each. Plans of mixed tiers (hexl_ks_plan::mixed; round 5): k_ksx_intt once
+// for the strict limbs and once for the lazy ones (an inverse transform has those two forms only), k_ksx_special in the special prime's
+// tier, k_ksx_main once per tier present among the decomposition limbs -- e.g. bridge-seal's chain 52,30,30,40,27,27,27
+// (experimental/bridge-seal/tests/seal_test.sh:20): limb 0 on the strict kernels, limbs 1-5 and the special prime at period 12, where
+// rounds 1-4 ran the strict 14-instruction butterflies on all seven because one of them is 52-bit.
+template <int LOGN, int LOGE, bool FUSED = false>
+static int run_chunk_x(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* ev) {
+    hipStream_t st = p->cur;
+    const u32 L = a.L;
+    const bool per_limb = p->mixed && LOGE == 4;
+    auto tier_of = [&](u32 i) { return per_limb ? (int)p->tier[i] : p->f64_lazy; };
+    // launch `stage` once per group of limbs that share key(tier)
+    auto per_group = [&](int stage, auto key) -> int {
+        bool done[16] = {};
+        for (u32 i0 = 0; i0 < L; ++i0) {
+            if (done[i0]) continue;
+            const int t0 = tier_of(i0);
+            a.nsel = 0; a.selmap = 0;
+            for (u32 i = i0; i < L; ++i)
+                if (!done[i] && key(tier_of(i)) == key(t0)) { done[i] = true; a.selmap |= (unsigned long long)i << (4 * a.nsel++); }
+            if (int rc = launch_stage_tier<LOGN, LOGE, FUSED>(p, a, stage, key(t0), p->x_skip)) return rc;
+        }
+        return 0;
+    };
+    // timing stages: 1 = step 1 (inverse transforms), 2 = special slot (steps 2-4), 4 = decomposition slots (steps 2-3, 5-7)
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1)
+        if (int rc = per_group(1, [](int t) { return t ? 3 : 0; })) return rc;
+    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (stage_mask & 2) {
+        a.nsel = L; a.selmap = 0xFEDCBA9876543210ull;
+        if (int rc = launch_stage_tier<LOGN, LOGE, FUSED>(p, a, 2, tier_of(a.K - 1), p->x_skip)) return rc;
+    }
+    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
+    if (stage_mask & 4)
+        if (int rc = per_group(4, [](int t) { return (LOGN == 14 && LOGE == 4 && !FUSED) ? t : (t ? 3 : 0); })) return rc;
     if (ev) HX_CHECK(hipEventRecord(ev[3], st));
     return (int)hipGetLastError();
 }
@@ -926,13 +994,6 @@ bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
     // L = 7 (tools/batch_sweep.py) the slot-major pipeline wins from 64 instances up (141 k against 132 k keyswitch/s), the
     // (b, d)-major one below 48
     return pipe == 3 || (pipe == 2 && ((4 * nb * p->L) << p->logn) >= ((7 * (size_t)p->ctx->num_cu) << 14));  // 3: always (tests)
-}
-
-template <int LOGN>
-static int launch_x_small(hexl_ks_plan* p, const KsArgsX& a, int stage_mask, hipEvent_t* ev) {
-    // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
-    if (!p->f64_lazy) return run_chunk_x<LOGN, 4, 0>(p, a, stage_mask, ev);
-    return p->x_skip ? run_chunk_x<LOGN, 4, 3, false, true>(p, a, stage_mask, ev) : run_chunk_x<LOGN, 4, 3>(p, a, stage_mask, ev);
 }
 
 // the plan's alias mask (profiling builds only; the shipped library ignores the variables)
@@ -965,25 +1026,15 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.key_stride = (a.alias & 1u) ? 0u : u32(2 * n);
     a.range_flag = p->d_flag;
     switch (p->logn) {
-        case 10: return launch_x_small<10>(p, a, stage_mask, ev);
-        case 11: return launch_x_small<11>(p, a, stage_mask, ev);
-        case 12: return launch_x_small<12>(p, a, stage_mask, ev);
-        case 13: return launch_x_small<13>(p, a, stage_mask, ev);
+        case 10: return run_chunk_x<10, 4>(p, a, stage_mask, ev);
+        case 11: return run_chunk_x<11, 4>(p, a, stage_mask, ev);
+        case 12: return run_chunk_x<12, 4>(p, a, stage_mask, ev);
+        case 13: return run_chunk_x<13, 4>(p, a, stage_mask, ev);
         case 14: break;
         default: return HEXL_E_BADARG;
     }
-    // LAZY template argument = forward reduction period of the transforms (f64_arith.hpp), as in keyswitch_f64.hip
-    if (p->x_loge == 5)                                           // 32 coefficients x 512 threads: measured slower, kept for study
-        return p->f64_lazy ? run_chunk_x<14, 5, 3>(p, a, stage_mask, ev) : run_chunk_x<14, 5, 0>(p, a, stage_mask, ev);
-    switch (p->f64_lazy * 2 + (p->x_skip ? 1 : 0)) {
-        case 25: return run_chunk_x<14, 4, 12, false, true>(p, a, stage_mask, ev);
-        case 24: return run_chunk_x<14, 4, 12>(p, a, stage_mask, ev);
-        case 13: return run_chunk_x<14, 4, 6, false, true>(p, a, stage_mask, ev);
-        case 12: return run_chunk_x<14, 4, 6>(p, a, stage_mask, ev);
-        case 7:  return run_chunk_x<14, 4, 3, false, true>(p, a, stage_mask, ev);
-        case 6:  return run_chunk_x<14, 4, 3>(p, a, stage_mask, ev);
-        default: return run_chunk_x<14, 4, 0>(p, a, stage_mask, ev);
-    }
+    // (the kernels' LAZY template argument = forward reduction period of the transforms, f64_arith.hpp: launch_stage_tier)
+    return p->x_loge == 5 ? run_chunk_x<14, 5>(p, a, stage_mask, ev) : run_chunk_x<14, 4>(p, a, stage_mask, ev);
 }
 
 // fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry).
@@ -992,11 +1043,7 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
 // (N = 32768 has no slot-major pipeline at all -- 64 registers of polynomial + 128 of accumulators do not fit a 1024-thread
 // workgroup.)
 template <int LOGN>
-static int mulrelin_for(hexl_ks_plan* p, const KsArgsX& a) {
-    // (moduli small enough for the longer lazy periods run with period 3 here: always valid, fewer kernel variants)
-    if (!p->f64_lazy) return run_chunk_x<LOGN, 4, 0, true>(p, a, 7, nullptr);
-    return p->x_skip ? run_chunk_x<LOGN, 4, 3, true, true>(p, a, 7, nullptr) : run_chunk_x<LOGN, 4, 3, true>(p, a, 7, nullptr);
-}
+static int mulrelin_for(hexl_ks_plan* p, const KsArgsX& a) { return run_chunk_x<LOGN, 4, true>(p, a, 7, nullptr); }
 int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t nb) {
     const size_t n = p->n, L = p->L;
     if (!p->use_f64 || !p->d_keys_x || p->x_loge != 4) return HEXL_E_BADARG;

@@ -425,4 +425,28 @@ struct WgNttF64 {
     }
 };
 
+// Per-limb arithmetic tier (round 5). A kernel built with LAZY >= 0 runs every transform on that one schedule (plans whose moduli share a
+// tier). Built with LAZY = -1 it looks the schedule up per limb: a workgroup of these kernels transforms modulo ONE q_i, so the choice is
+// one wave-uniform branch around the transform (the variants it does not take cost instruction-cache space only; these are the
+// small-batch kernels, one or two transforms per workgroup). WIDE: the ring dimension has kernels for all four periods (N = 16384);
+// elsewhere 6 and 12 run as 3, which is always valid.
+template <int V> struct TierC { static constexpr int value = V; };
+template <int LAZY, bool WIDE, class F>
+__device__ __forceinline__ void with_tier(unsigned long long tiermap, u32 limb, F f) {
+    if constexpr (LAZY >= 0) {
+        f(TierC<LAZY>{});
+    } else {
+        const u32 t = __builtin_amdgcn_readfirstlane(u32(tiermap >> (4 * limb)) & 15u);
+        if constexpr (WIDE) {
+            if (t == 12) f(TierC<12>{});
+            else if (t == 6) f(TierC<6>{});
+            else if (t == 3) f(TierC<3>{});
+            else f(TierC<0>{});
+        } else {
+            if (t != 0) f(TierC<3>{});
+            else f(TierC<0>{});
+        }
+    }
+}
+
 }  // namespace hx

@@ -119,6 +119,12 @@ int hexl_ks_range_check(hexl_ks_plan* plan);
  *   d_out must not overlap d_a or d_b (component 0 is stored before component 1's operands are read): HEXL_E_BADARG. */
 int hexl_multiply_relinearize(hexl_ks_plan* plan, uint64_t* d_out, const uint64_t* d_a,
                               const uint64_t* d_b, size_t batch);
+/* Arithmetic tier per limb (introspection for logs and tests): tiers[i], i < key_modulus_size, = the forward transforms' range-
+ * reduction period modulo q_i on the FP64 path -- 12 / 6 / 3 for q_i <= 2^49 / 2^50 / 2^51 (1 + 2^-7), 0 = every value reduced after
+ * every operation (q_i up to 2^52); -1 for every limb of a plan on the integer kernels (a modulus >= 2^52). Every transform runs modulo
+ * ONE q_i and takes that limb's tier, as each NTT engine of the reference runs on its own modulus (device/keyswitch/ntt_core.hpp:285-291);
+ * HEXL_KS_PER_LIMB=0 gives every limb the tier of the plan's largest modulus. Returns 1 when the limbs in use differ in tier, else 0. */
+int hexl_ks_plan_tiers(const hexl_ks_plan* plan, int* tiers /* [key_modulus_size] */);
 /* bytes of HBM scratch a batch of `batch` keyswitches needs (for capacity planning) */
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan* plan, size_t batch);
 

@@ -514,6 +514,78 @@ static void test_prime_wide(uint64_t p) {
     }
 }
 
+// ---- round 5: plans whose limbs differ in tier ------------------------------------------------------------------
+// Every transform of the keyswitch runs modulo ONE q_i, and since round 5 in the tier of THAT modulus (hexl_ks_plan::tier) instead of the
+// tier of the plan's largest one. What is new on the arithmetic side is which values meet which modulus: c_d, canonical modulo a 52-bit
+// q_d, range-reduced by a 27-bit q_i (a quotient of 25 bits out of one rounded multiply) and then transformed at reduction period 12;
+// the centred remainder of a 27-bit special prime entering a strict 52-bit limb, and of a 52-bit one entering a 27-bit limb. This replays,
+// for every ordered pair (q_d -> q_i) of a chain, the non-SKIP mod-up round of keyswitch_x.hip / keyswitch_f64.hip / keyswitch_lat.hip --
+// reduce, forward transform in q_i's tier without the reduction after the last stage, multiply-accumulate in q_i's form (folded with
+// the accumulator at its bound; strict limbs: the strict fold) -- and the mod-down input, against the oracle and 128-bit integers.
+static double g_mixed_max = 0;
+static inline void trackm(double x) { double a = x < 0 ? -x : x; if (a > g_mixed_max) g_mixed_max = a; }
+static void test_mixed_chain(uint64_t n, const std::vector<uint64_t>& chain, bool adversarial) {
+    int logn = 0; while ((1ull << logn) < n) ++logn;
+    for (size_t ii = 0; ii < chain.size(); ++ii) {
+        const uint64_t p = chain[ii];
+        const hxf::Mod m{(double)p, 1.0 / (double)p};
+        const int period = hxf::lazy_period_for((double)p);          // 0 = strict: what hexl_ks_plan_create gives limb ii
+        std::vector<uint64_t> blk(4 * n);
+        orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+        const uint64_t* roots = blk.data() + 2 * n;
+        auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+        std::vector<uint64_t> key(n);
+        orc_fill_splitmix(key.data(), n, p ^ 0x2718, p);
+        for (size_t dd = 0; dd <= chain.size(); ++dd) {
+            if (dd == ii) continue;
+            // dd < size: c_d canonical modulo q_d; dd == size: y = s' - floor(q_sp/2) of EVERY other modulus as special prime (centred)
+            std::vector<double> u(n);
+            std::vector<uint64_t> ref(n);
+            const uint64_t qd = dd < chain.size() ? chain[dd] : chain[(ii + 1) % chain.size()];
+            for (uint64_t i = 0; i < n; ++i) {
+                double in;
+                if (dd < chain.size()) {
+                    const uint64_t x = adversarial ? qd - 1 - (i & 3) : rnd() % qd;
+                    in = hxf::to_f64_lt52(x);
+                    ref[i] = x % p;
+                } else {
+                    const int64_t y = adversarial ? ((i & 1) ? 1 : -1) * (int64_t)(qd / 2) : (int64_t)(rnd() % qd) - (int64_t)(qd / 2);
+                    in = (double)y;
+                    ref[i] = (uint64_t)centred((i128)y, (int64_t)p);
+                }
+                u[i] = hxf::reduce(in, m);                                   // intt1_redu.hpp:36-42 / intt2_redu.hpp:49-51 (non-SKIP kernels)
+                trackm(in); trackm(u[i]);
+                CHECK((u[i] < 0 ? -u[i] : u[i]) <= 0.5 * (double)p + 2.0, "mixed reduce q_d=%lu -> p=%lu i=%lu: %.0f", qd, p, i, u[i]);
+            }
+            orc_ks_ntt(ref.data(), n, p, roots);
+            int s = 1;
+            for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
+                const bool red = period == 0 || hxf::lazy_fwd_reduce_after(s, 0, period);       // FINAL = false: no reduction after the last stage
+                for (uint64_t i = 0; i < mm; ++i) {
+                    const double w = centre(roots[mm + i]);
+                    for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                        if (red) hxf::ct_bfly(u[j], u[j + t], w, m); else hxf::ct_bfly_lazy(u[j], u[j + t], w, m);
+                        trackm(u[j]); trackm(u[j + t]);
+                    }
+                }
+            }
+            for (uint64_t i = 0; i < n; ++i) {
+                CHECK(hxf::from_f64(hxf::lift(hxf::reduce(u[i], m), m)) == ref[i], "mixed fwd q_d=%lu -> p=%lu (period %d) i=%lu", qd, p, period, i);
+                const uint64_t kv = adversarial ? ((i & 1) ? p / 2 : p / 2 + 1) : key[i];
+                const double kc = centre(kv);
+                const double bound = period == 0 ? 0.9 : 1.6;                // accumulator bounds of mac_fold's two tiers (f64_arith.hpp)
+                const double acc0 = ((u[i] < 0) != (kc < 0) ? -1.0 : 1.0) * (double)(uint64_t)(bound * (double)p);
+                const double acc = hxf::mac_fold(acc0, u[i], kc, m);
+                trackm(acc);
+                const i128 exact = (i128)(int64_t)acc0 + (i128)(int64_t)u[i] * (int64_t)kc;
+                CHECK(acc == (double)(int64_t)acc && centred(exact - (int64_t)acc, (int64_t)p) == 0 &&
+                      (acc < 0 ? -acc : acc) <= (period == 0 ? 0.9 : 1.7) * (double)p + 2.0,
+                      "mixed mac_fold q_d=%lu -> p=%lu i=%lu acc=%.0f", qd, p, i, acc);
+            }
+        }
+    }
+}
+
 int main() {
     std::vector<uint64_t> primes;
     uint64_t tmp[8];
@@ -614,6 +686,31 @@ int main() {
         }
         std::printf("strict kernels at 2^52 <= p < 2^52 * 1.125 (%lu, %lu): max |x| seen = 2^%.3f (limit 2^53)\n", wide[0], wide.back(), log2(g_wide_max));
         CHECK(g_wide_max < 9007199254740992.0, "strict wide bound exceeded");
+    }
+    // round 5, limbs of different tiers: bridge-seal's chain (largest primes = 1 mod 2n below 2^52, 2^30, 2^30, 2^40, 2^27, 2^27, 2^27;
+    // seal_test.sh:20) and a ladder through all four tiers, every ordered pair of moduli
+    {
+        for (uint64_t n : {1024ull, 16384ull}) {
+            std::vector<uint64_t> seal, ladder;
+            for (int b : {52, 30, 30, 40, 27, 27, 27})
+                for (uint64_t v = (1ull << b) - 2 * n + 1;; v -= 2 * n) {
+                    bool used = false;
+                    for (uint64_t q : seal) used = used || q == v;
+                    if (!used && orc_is_prime(v)) { seal.push_back(v); break; }
+                }
+            for (int b : {52, 51, 50, 49, 44})
+                for (uint64_t v = (1ull << b) - 2 * n + 1;; v -= 2 * n)
+                    if (orc_is_prime(v)) { ladder.push_back(v); break; }
+            if (n == 16384) CHECK(seal[0] == 4503599626682369ull && seal[6] == 132612097ull, "seal chain primes %lu %lu", seal[0], seal[6]);
+            CHECK(hxf::lazy_period_for((double)seal[0]) == 0 && hxf::lazy_period_for((double)seal[3]) == 12 && hxf::lazy_period_for((double)seal[6]) == 12,
+                  "seal chain tiers");
+            CHECK(hxf::lazy_period_for((double)ladder[1]) == 3 && hxf::lazy_period_for((double)ladder[2]) == 6 && hxf::lazy_period_for((double)ladder[3]) == 12,
+                  "ladder tiers");
+            for (int adv = 0; adv < 2; ++adv) { test_mixed_chain(n, seal, adv); test_mixed_chain(n, ladder, adv); }
+        }
+        std::printf("limbs of different tiers (seal chain 52,30,30,40,27,27,27 + four-tier ladder, every pair): max |x| seen = 2^%.3f (limit 2^53)\n",
+                    log2(g_mixed_max));
+        CHECK(g_mixed_max < 9007199254740992.0, "mixed-tier bound exceeded");
     }
     std::printf("folded multiply-accumulate: max |acc| / p seen = %.3f (bound 1.6)\n", g_fold_max);
     std::printf(failures ? "F64 SELFTEST: %d FAILURE(S)\n" : "F64 SELFTEST: ALL PASSED (%d primes)\n", failures ? failures : (int)primes.size());

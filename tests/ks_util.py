@@ -52,6 +52,31 @@ def primes_below(orc, count, limit, n):
     return out
 
 
+def seal_chain(orc, K, n):
+    """K key moduli shaped like bridge-seal's run (experimental/bridge-seal/tests/seal_test.sh:20: CoeffModulus::Create(16384,
+    {52, 30, 30, 40, 27, 27, 27}), SEAL picks the LARGEST primes = 1 mod 2n below each 2^bits): a 52-bit first limb (strict FP64 tier)
+    followed by 30 / 30 / 40 / 27 / 27 / 27-bit ones (reduction period 12), the last one being the special prime"""
+    bits = [52, 30, 30, 40, 27, 27, 27]
+    bits = (bits + bits[1:] * 3)[:K]
+    out = []
+    for b in bits:
+        k = 1 + sum(1 for v in out if v < (1 << b) and v > (1 << (b - 1)))          # the next-largest prime of that size not used yet
+        out.append(primes_below(orc, k, 1 << b, n)[k - 1])
+    return out
+
+
+def tier_ladder(orc, K, n):
+    """K distinct key moduli that walk through all four FP64 tiers (strict, period 3, 6, 12): the largest unused primes below
+    2^52, 2^51, 2^50, 2^49, 2^44, 2^50, ...; the special prime (last) is a 49-bit one"""
+    out = []
+    for b in ([52, 51, 50, 49, 44, 50, 51, 52] * 2)[:K - 1] + [49]:
+        k = 1
+        while primes_below(orc, k, 1 << b, n)[k - 1] in out:
+            k += 1
+        out.append(primes_below(orc, k, 1 << b, n)[k - 1])
+    return out
+
+
 class RlweCase:
     """Real RLWE switching keys with special prime P = moduli[K-1]: key d, limb i holds (b, a) with
     b = -a*s_old + e + (i == d ? P : 0) * s_new in the NTT domain. check(res) asserts that

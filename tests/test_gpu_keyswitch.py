@@ -4,7 +4,7 @@ tests/test_keyswitch.cpp:148-191 (vectors 16384_6_7_7_2 / 8192_.., one worksize 
 import numpy as np
 import pytest
 
-from ks_util import KsCase, primes_below
+from ks_util import KsCase, primes_below, seal_chain, tier_ladder
 
 pytestmark = pytest.mark.gpu
 from pathlib import Path  # noqa: E402
@@ -444,6 +444,21 @@ TIERS = {
     "noskip_period3_mixed_51_and_30bit": ({}, "orc.primes(2, 51, n)[:1] + orc.primes(K - 2, 30, n) + orc.primes(2, 51, n)[1:]"),
     "strict_just_below_2^52": ({}, "primes_below(orc, K, 1 << 52, n)"),
     "strict_forced_51bit": ({"HEXL_KS_NOLAZY": "1"}, "None"),
+    # round 5: plans whose limbs differ in tier -- every transform takes the tier of ITS modulus (hexl_ks_plan::tier; the reference's NTT
+    # engines each run on their own modulus, device/keyswitch/ntt_core.hpp:285-291)
+    "mixed_seal_chain_strict_and_period12": ({}, "seal_chain(orc, K, n)"),
+    "mixed_seal_chain_plan_wide_tier": ({"HEXL_KS_PER_LIMB": "0"}, "seal_chain(orc, K, n)"),
+    "mixed_special_prime_strict_rest_period12": ({}, "orc.primes(K - 1, 47, n) + primes_below(orc, 1, 1 << 52, n)"),
+    "mixed_skip_period6_and_period3_around_2^50": ({}, "(primes_below(orc, K, 1 << 50, n) + orc.primes(K, 50, n))[K // 2:K // 2 + K]"),
+    "mixed_all_four_tiers": ({}, "tier_ladder(orc, K, n)"),
+}
+# what plan.tiers() must report for the first K = 4 limbs of the round-5 entries at n = 16384 (test_per_limb_tiers_reported)
+MIXED_TIERS_K4 = {
+    "mixed_seal_chain_strict_and_period12": ([0, 12, 12, 12], True),
+    "mixed_seal_chain_plan_wide_tier": ([0, 0, 0, 0], False),
+    "mixed_special_prime_strict_rest_period12": ([12, 12, 12, 0], True),
+    "mixed_skip_period6_and_period3_around_2^50": ([6, 6, 3, 3], True),
+    "mixed_all_four_tiers": ([0, 3, 6, 12], True),
 }
 
 
@@ -460,11 +475,45 @@ def test_lone_keyswitch_latency_path(tier, L, K):
     """keyswitch_lat.hip: a lone keyswitch at N = 16384 runs every transform as four quarter transforms on four compute units
     (HEXL_KS_LAT=2 sends every instance of a batch down that path, one by one): same bits as the oracle in every tier"""
     env, moduli = TIERS[tier]
-    if (L, K) in ((5, 7), (15, 16)) and tier not in ("skip_period3_51bit", "strict_just_below_2^52", "noskip_forced_period3_51bit"):
-        pytest.skip("shape covered in three tiers")
+    if (L, K) in ((5, 7), (15, 16)) and tier not in ("skip_period3_51bit", "strict_just_below_2^52", "noskip_forced_period3_51bit",
+                                                      "mixed_seal_chain_strict_and_period12"):
+        pytest.skip("shape covered in four tiers")
     if K < 3 and "mixed_50_to_40bit" in tier:
         pytest.skip("the mixed tier needs three key moduli")
     _alternative(dict(env, HEXL_KS_LAT="2"), 16384, L, K, 3, moduli)
+
+
+@pytest.mark.parametrize("tier", [t for t in TIERS if t.startswith("mixed_")])
+@pytest.mark.parametrize("n,L,K,nb,env", [(16384, 6, 7, 5, {"HEXL_KS_LAT": "0"}),                       # five kernels, one transform per workgroup
+                                          (16384, 3, 4, 160, {"HEXL_KS_PIPE": "1"}),                    # large batch kept off the slot-major pipeline
+                                          (16384, 6, 7, 2, {"HEXL_KS_LAT": "1"}),                       # the three-kernel path (k_ksl_*)
+                                          (32768, 3, 4, 6, {}), (4096, 3, 4, 9, {"HEXL_KS_LAT": "0"})])
+def test_bd_major_kernels_with_limbs_of_different_tiers(tier, n, L, K, nb, env):
+    """keyswitch_f64.hip: the (b, d)-major kernels built with LAZY = -1 look the reduction schedule up per transform (with_tier)"""
+    tenv, moduli = TIERS[tier]
+    _alternative(dict(tenv, **env), n, L, K, nb, moduli)
+
+
+def test_per_limb_tiers_reported(hx, ctx, orc):
+    """hexl_ks_plan_tiers: the tier every limb's transforms run in, and whether the limbs in use differ"""
+    n, L, K = 16384, 3, 4
+    for name, (want, mixed) in MIXED_TIERS_K4.items():
+        env, expr = TIERS[name]
+        if env:
+            continue                                              # (environment knobs are read per plan, but keep this test in-process)
+        moduli = eval(expr, {"orc": orc, "n": n, "K": K, "primes_below": primes_below, "seal_chain": seal_chain, "tier_ladder": tier_ladder})
+        case = KsCase(orc, n, L, K, seed=3, moduli=moduli)
+        plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+        assert plan.tiers() == (want, mixed), name
+        plan.close()
+    case = KsCase(orc, n, L, K, seed=3)                           # BASELINE's primes: one tier, nothing mixed
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    assert plan.tiers() == ([3, 3, 3, 3], False)
+    plan.close()
+    case = KsCase(orc, n, L, K, seed=3, bits=55)                  # integer kernels
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
+    assert plan.tiers() == ([-1, -1, -1, -1], False)
+    plan.close()
 
 
 def test_latency_paths_agree_on_one_keyswitch(hx, ctx, dev, orc):
@@ -495,7 +544,7 @@ def _alternative(env, n, L, K, nb, moduli="None"):
 import sys
 sys.path[:0] = [%r, %r, %r]
 import numpy as np, torch, hexl_fpga_amd as hx, orc
-from ks_util import KsCase, primes_below
+from ks_util import KsCase, primes_below, seal_chain, tier_ladder
 dev = torch.device("cuda:0"); ctx = hx.Context(0)
 n, L, K, nb = %d, %d, %d, %d
 case = KsCase(orc, n, L, K, seed=77, moduli=%s)

@@ -61,6 +61,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dres, res.data(), res.size() * 8, hipMemcpyHostToDevice);
     a.mods = dm; a.tables = dt; a.keys = dk; a.c = dc; a.s = ds; a.t_target = dtt; a.result = dres;
     a.L = L; a.K = K; a.nb = nb; a.stamps = dst; a.key_stride = 2u << 14; a.alias = 0; a.range_flag = dflag;
+    a.nsel = L; a.selmap = 0xFEDCBA9876543210ull;                    // every limb in one launch (plans of one tier)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto kin = k_ksx_intt<14, KX_LOGE, 3>;
     hipFuncSetAttribute((const void*)kin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
