@@ -231,6 +231,14 @@ def cxx_api_end_to_end(L, timeout_s=120):
             out[f"worksize_{ws}"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-200:]}
         except Exception as e:                                       # a reported extra: never fails the benchmark
             out[f"worksize_{ws}"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+    # the reference's own SEAL workload at the bridge's worksize 1: relinearise (6 of 7 key moduli) and rotate (5 of 7), chain 52,30,30,40,27,27,27
+    for name, Lx in (("seal_chain_relinearize_L6_K7_worksize_1", 6), ("seal_chain_rotate_L5_K7_worksize_1", 5)):
+        try:
+            r = subprocess.run([str(exe), "1", str(Lx), "0", "1", "seal"], capture_output=True, text=True, timeout=timeout_s)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[name] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     out["note"] = ("host-pointer API of include/hexl-fpga.h on one GPU, decomp %d: PCIe-bound (0.8 MB up + 1.6 MB down per keyswitch at L = 6); "
                    "device-resident callers run at `value`" % L)
     return out

@@ -19,7 +19,8 @@ int hx_reserve_device(hexl_ctx* ctx, void** p, size_t* cur, size_t need) {
 int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need) {
     if (*cur >= need) return 0;
     if (*p) { HX_CHECK(hipStreamSynchronize(ctx->stream)); HX_CHECK(hipHostFree(*p)); *p = nullptr; *cur = 0; }
-    HX_CHECK(hipHostMalloc(p, need, hipHostMallocDefault));
+    // coherent (fine-grained): the zero-copy lone keyswitch reads result limbs the running kernel has just published (keyswitch_host_lone)
+    HX_CHECK(hipHostMalloc(p, need, hipHostMallocCoherent));
     *cur = need;
     return 0;
 }
@@ -261,9 +262,11 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     // input-range flag of the FP64 kernels (hexl_ks_range_check) + its pinned mirror; HEXL_KS_VALIDATE shares them
-    HX_CHECK(hipMalloc((void**)&p->d_flag, sizeof(u32)));
-    HX_CHECK(hipMemset(p->d_flag, 0, sizeof(u32)));
-    HX_CHECK(hipHostMalloc((void**)&p->h_flag, sizeof(u32), hipHostMallocDefault));
+    // word 0: the kernels' range flag (HEXL_W_RANGE); word 1: HEXL_KS_VALIDATE's own (HEXL_E_RANGE) -- two statuses, two words
+    // (word 2: the output gate of the zero-copy lone keyswitch, keyswitch_lat.hip k_ksq_down)
+    HX_CHECK(hipMalloc((void**)&p->d_flag, 4 * sizeof(u32)));
+    HX_CHECK(hipMemset(p->d_flag, 0, 4 * sizeof(u32)));
+    HX_CHECK(hipHostMalloc((void**)&p->h_flag, 2 * sizeof(u32), hipHostMallocDefault));
     HX_CHECK(hipMalloc((void**)&p->d_mods, K * sizeof(KsModulus)));
     HX_CHECK(hipMalloc((void**)&p->d_tables, tables.size() * sizeof(u64)));
     // integer-kernel keys (key words + Shoup factors): only plans that run the integer kernels hold them
@@ -592,8 +595,9 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     const auto t_begin = std::chrono::steady_clock::now();
     auto stamp = [&](const char* what, size_t k) {
         if (trace)
-            fprintf(stderr, "[hexl host] %-22s sub-batch %zu  +%8.1f us\n", what, k,
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+            fprintf(stderr, "[hexl host] %-22s sub-batch %zu  +%8.1f us  @%12.1f us\n", what, k,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(),
+                    fmod(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1e8));
     };
     // at least four sub-batches once there are four items, so that the stages overlap for small windows too
     const size_t S = std::min(sh.sub, std::max<size_t>(1, (batch + 3) / 4));
@@ -807,6 +811,102 @@ extern "C" int hexl_dyadic_multiply_host(hexl_ctx* c, uint64_t* const* h_out, co
         [&](size_t first, size_t cnt, const char* h) { parallel_for(cnt, [&](size_t k) { memcpy(h_out[first + k], h + k * out1, out1); }); });
 }
 
+// A LONE keyswitch (the SEAL bridge's call shape: set_worksize_KeySwitch(1), experimental/bridge-seal/tests/fpga_context.h:13-16) through
+// the host-pointer entry point, ZERO-COPY (round 5). The staged pipeline spent 212 us per call at L = 6: pack 10, seven enqueues 22,
+// [hipMemcpyAsync 0.8 MB up 29.5, four kernels 50, hipMemcpyAsync 1.6 MB down 43, gaps] 121, host accumulate 37, hand-overs 20
+// (HEXL_HOST_TRACE=1). Here the kernels of the quarter-transform path (keyswitch_lat.hip) work on the pinned slabs themselves:
+// k_ksq_intt pulls t_target across PCIe while it transforms, k_ksq_down pushes the output the same way (tools/zero_copy_probe: 18.7 us
+// and 31.6 us for those bytes, overlapped with the arithmetic, against 29.5 + 43.2 us of copies around it) and publishes every finished
+// quarter limb in a pinned word, so the host adds limb i into the caller's `result` (the reference's contract: the HOST accumulates,
+// FPGAObject_KeySwitch::fill_out_data, fpga.cpp:441-475) while limbs i + 1 ... are still in flight. No copy engine, no memset, no
+// stream synchronisation on the critical path; the range flag is a pinned word too.
+static int keyswitch_host_lone(hexl_ks_plan* p, uint64_t* const* h_results, const uint64_t* const* h_t_targets, size_t batch) {
+    hexl_ctx* c = p->ctx;
+    const size_t n = p->n, L = p->L, tt = L * n * 8, rs = 2 * tt;
+    static const bool trace = [] { const char* e = getenv("HEXL_HOST_TRACE"); return e && atoi(e) == 1; }();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace)
+            fprintf(stderr, "[hexl host] %-22s zero-copy    +%8.1f us  @%12.1f us\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(),
+                    fmod(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1e8));
+    };
+    const size_t in_bytes = (batch * tt + 255) & ~size_t(255), out_bytes = (batch * rs + 255) & ~size_t(255);
+    const size_t nflag = batch * 2 * L * 4;                                   // one word per quarter limb
+    int rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, in_bytes + out_bytes + 256 + nflag * sizeof(u32));
+    if (rc) return rc;
+    char* h_in = (char*)c->h_stage;
+    char* h_out = h_in + in_bytes;
+    u32* flag = (u32*)(h_out + out_bytes);
+    u32* done = flag + 64;
+    for (size_t b = 0; b < batch; ++b) memcpy(h_in + b * tt, h_t_targets[b], tt);
+    __atomic_store_n(flag, 0u, __ATOMIC_RELAXED);                             // flag[0]: input-range flag, flag[1]: "the last kernel has started"
+    __atomic_store_n(flag + 1, 0u, __ATOMIC_RELAXED);
+    memset(done, 0, nflag * sizeof(u32));
+    stamp("packed");
+    const u32 epoch = ++c->lone_epoch ? c->lone_epoch : ++c->lone_epoch;      // never 0
+    p->host_done = done; p->host_flag = flag; p->host_epoch = epoch; p->overwrite_result = true;
+    rc = hexl_keyswitch(p, (u64*)h_out, (const u64*)h_in, batch);              // pinned slabs: device-visible at their host addresses
+    p->host_done = nullptr; p->host_flag = nullptr; p->overwrite_result = false;
+    if (rc) return rc;
+    stamp("enqueued");
+    bool distinct = true;                                                     // aliased results must be added in order
+    for (size_t a = 0; a < batch && distinct; ++a)
+        for (size_t b = a + 1; b < batch; ++b)
+            if (h_results[a] == h_results[b]) { distinct = false; break; }
+    auto add_limb = [&](u64* res, const u64* out, size_t limb) {                // limb = k * L + i
+        const u64 q = p->moduli[limb % L];
+        const u64* o = out + limb * n;
+        u64* r = res + limb * n;
+        for (size_t j = 0; j < n; ++j) { const u64 v = r[j] + o[j]; r[j] = v - (q & (0 - (u64)(v >= q))); }
+    };
+    // a quarter limb has landed when its word shows this call's epoch (released by the kernel behind the data); a launch that died
+    // never publishes: give up after the stream has gone idle without it
+    std::atomic<bool> lost{false};
+    auto wait_limb = [&](size_t x) -> bool {                                    // x = b * 2L + limb
+        for (int qd = 0; qd < 4; ++qd) {
+            const u32* w = done + x * 4 + qd;
+            for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != epoch; ++spins) {
+                if (lost.load(std::memory_order_relaxed)) return false;
+                if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(c->stream) != hipErrorNotReady &&
+                    __atomic_load_n(w, __ATOMIC_ACQUIRE) != epoch) { lost.store(true); return false; }
+                __builtin_ia32_pause();
+            }
+        }
+        return true;
+    };
+    auto wait_word = [&](const u32* w) -> bool {
+        for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != epoch; ++spins) {
+            if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(c->stream) != hipErrorNotReady && __atomic_load_n(w, __ATOMIC_ACQUIRE) != epoch) {
+                lost.store(true);
+                return false;
+            }
+            __builtin_ia32_pause();
+        }
+        return true;
+    };
+    if (distinct) {
+        // the calling thread alone until the LAST kernel starts (its arithmetic takes ~15 us before the first limb crosses PCIe) ...
+        wait_word(flag + 1);
+        stamp("last kernel started");
+        // ... then one job per limb: the pool's workers wake up during that arithmetic and add limb x while limbs x + 1 ... are in flight
+        parallel_for(batch * 2 * L, [&](size_t x) { if (wait_limb(x)) add_limb(h_results[x / (2 * L)], (const u64*)(h_out + (x / (2 * L)) * rs), x % (2 * L)); });
+    } else {
+        HX_CHECK(hipStreamSynchronize(c->stream));
+        for (size_t b = 0; b < batch; ++b)
+            for (size_t limb = 0; limb < 2 * L; ++limb) add_limb(h_results[b], (const u64*)(h_out + b * rs), limb);
+    }
+    if (lost.load()) {
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[hexl_mi355x] lone keyswitch: the launch finished without publishing its results (%s)\n", hipGetErrorString(e));
+        return e != hipSuccess ? (int)e : (int)hipErrorUnknown;
+    }
+    // every quarter limb of the LAST kernel has been published, so the launch is over as far as these slabs and the plan's scratch
+    // are concerned; the next launch on the stream is ordered behind it anyway
+    stamp("done");
+    return __atomic_load_n(flag, __ATOMIC_ACQUIRE) ? HEXL_W_RANGE : 0;
+}
+
 extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, const uint64_t* const* h_t_targets,
                                    size_t batch) {
     if (!p || !h_results || !h_t_targets) return HEXL_E_BADARG;
@@ -822,6 +922,9 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
         // being contiguous or a result array repeats (two instances of one launch must not update the same words;
         // launches on one stream are ordered, which keeps the reference's submission-order semantics)
         int rc = 0;
+        // the status covers THIS call's objects, as on the staged path below: whatever an earlier hexl_keyswitch on the plan left in
+        // the flag is for hexl_ks_range_check before this call (only the staged branch cleared it)
+        if (p->use_f64) HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), c->stream));
         for (size_t i = 0, j; !rc && i < batch; i = j) {
             for (j = i + 1; j < batch && h_results[j] == h_results[j - 1] + rs / 8 &&
                             h_t_targets[j] == h_t_targets[j - 1] + tt / 8; ++j) {}
@@ -831,6 +934,11 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
         if (!rc) rc = p->use_f64 ? hexl_ks_range_check(p) : (int)hipStreamSynchronize(c->stream);
         return rc;
     }
+    // a lone keyswitch (or the few that still take the quarter-transform path): zero-copy, no staging pipeline. HEXL_HOST_ZERO_COPY=0
+    // keeps the staged route (comparisons)
+    static const bool zero_copy = [] { const char* e = getenv("HEXL_HOST_ZERO_COPY"); return !(e && atoi(e) == 0); }();
+    if (zero_copy && p->use_f64 && p->have_keys && batch <= 8 && hx_ks_lat_applies(p, batch) && hx_ks_can_overwrite(p, batch))
+        return keyswitch_host_lone(p, h_results, h_t_targets, batch);
     // The FP64 kernels flag t_target words that are not below their modulus (the device-side result buffer starts at zero or
     // is written here, so `result` is the host's business). The status covers THIS call: the flag is cleared on the stream
     // before the first launch (whatever earlier hexl_keyswitch launches on the plan left in it is for hexl_ks_range_check,

@@ -242,4 +242,53 @@ HX_HD constexpr int lazy_period_for(double max_modulus) {
     return max_modulus <= 562949953421312.0 ? 12 : max_modulus <= 1125899906842624.0 ? 6 : max_modulus <= LAZY_MAX_MODULUS ? 3 : 0;
 }
 
+
+// ---- the bound chains above, evaluated at compile time -----------------------------------------------------------------
+// The lazy schedules are exact only while every intermediate stays below 2^53 = p / a, a = p 2^-53. The margins are thin at the top of
+// each tier (3.77p of 3.97p), and they depend on constants that live in different places -- LAZY_MAX_MODULUS, the tier boundaries of
+// lazy_period_for, LAZY_SKIP_MAX_RATIO, INV_NOWP_STRICT_STAGE, the accumulator bound of mac_fold -- so the recurrences are replayed here
+// with static_asserts: changing a ratio, a tier boundary or a period without re-deriving the bounds fails the build instead of relying on
+// the randomised host replay (tests/cpp/f64_selftest.cpp) to notice. `a` is taken at the LARGEST modulus of the tier (the worst case).
+namespace bounds {
+constexpr double TWO53 = 9007199254740992.0;
+constexpr double tier_top(int period) { return period == 12 ? 562949953421312.0 : period == 6 ? 1125899906842624.0 : LAZY_MAX_MODULUS; }
+constexpr double tier_a(int period) { return tier_top(period) / TWO53; }
+constexpr double SLOP = 1e-9;                                      // the "+ 2" of "|x| <= p/2 + 2" relative to p >= 2^48 ... and to spare
+// forward butterflies without a range reduction: |x| <= c p  ->  (1 + 1.5 a) c + 0.5 per stage
+constexpr double fwd_chain(double c, double a, int stages) {
+    for (int s = 0; s < stages; ++s) c = (1.0 + 1.5 * a) * c + 0.5;
+    return c;
+}
+// inverse butterflies whose quotient comes from the product (gs_bfly_lazy_nowp): product outputs y -> 0.5 + 3 a y, |X - Y| <= 2 y
+constexpr double inv_chain(double y, double a, int stages) {
+    for (int s = 0; s < stages; ++s) y = 0.5 + 3.0 * a * y;
+    return y;
+}
+constexpr double MAC_FOLD_ACC = 1.7;                               // |acc| handed to the mod-down epilogue by mac_fold (lazy tiers)
+constexpr bool tier_ok(int period) {
+    const double a = tier_a(period), limit = 1.0 / a;
+    // (i) standard schedule: the sums of `period` stages from a centred value (the last of them is the one that gets reduced)
+    if (!(fwd_chain(0.5 + SLOP, a, period) < limit)) return false;
+    // (ii) shifted schedule (SKIP mod-up): a canonical residue of a neighbouring modulus, rho p; the first group is period - 1 stages
+    if (!(fwd_chain(LAZY_SKIP_MAX_RATIO, a, period - 1) < limit)) return false;
+    // (iii) SKIP mod-down: the centred special-prime remainder, 0.5 rho p, on the standard schedule for `period` stages
+    if (!(fwd_chain(0.5 * LAZY_SKIP_MAX_RATIO + SLOP, a, period) < limit)) return false;
+    // (iv) mod-down epilogue: un-reduced accumulator minus an un-reduced transform tail of at most period - 1 stages
+    if (!(MAC_FOLD_ACC + fwd_chain(0.5 + SLOP, a, period - 1) < limit)) return false;
+    return true;
+}
+static_assert(tier_ok(3), "period 3 tier (p <= LAZY_MAX_MODULUS): a forward bound chain passes 2^53");
+static_assert(tier_ok(6), "period 6 tier (p <= 2^50): a forward bound chain passes 2^53");
+static_assert(tier_ok(12), "period 12 tier (p <= 2^49): a forward bound chain passes 2^53");
+static_assert(lazy_period_for(tier_top(3)) == 3 && lazy_period_for(tier_top(6)) == 6 && lazy_period_for(tier_top(12)) == 12 &&
+              lazy_period_for(tier_top(3) + 1.0) == 0, "tier boundaries of lazy_period_for moved: re-derive tier_top");
+// inverse transforms without the w/p table: INV_NOWP_STRICT_STAGE - 1 lazy stages in front of the strict stage, at most
+// 15 - 1 - INV_NOWP_STRICT_STAGE behind it (n <= 2^15; the last stage is the fused scaling on reduced sums), each with 2 y < 2^53 / p
+static_assert(2.0 * inv_chain(0.5 + SLOP, tier_a(3), INV_NOWP_STRICT_STAGE - 1) < 1.0 / tier_a(3), "inverse chain in front of the strict stage");
+static_assert(2.0 * inv_chain(0.5 + SLOP, tier_a(3), 15 - 1 - INV_NOWP_STRICT_STAGE) < 1.0 / tier_a(3), "inverse chain behind the strict stage");
+// canonical inputs taken as they are (rho p: the standalone _INTT fast path and k_ksx_intt with rho = 1): the first stage's product input
+static_assert(LAZY_SKIP_MAX_RATIO < 1.0 / tier_a(3) && 2.0 * inv_chain(LAZY_SKIP_MAX_RATIO, tier_a(3), INV_NOWP_STRICT_STAGE - 1) < 1.0 / tier_a(3),
+              "inverse chain from un-centred inputs");
+}  // namespace bounds
+
 }  // namespace hxf

@@ -50,6 +50,7 @@ struct hexl_ctx {
     void* d_stage = nullptr;  size_t d_stage_bytes = 0;
     void* d_shared = nullptr; size_t d_shared_bytes = 0;   // small shared arrays of device-resident callers
     void* h_stage = nullptr;  size_t h_stage_bytes = 0;
+    uint32_t lone_epoch = 0;                                // zero-copy lone keyswitches so far (their completion words carry it)
     // host-pointer pipeline: copy streams + events (created lazily), see run_pipeline() in capi.hip
     hipStream_t s_up = nullptr, s_down = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
@@ -125,12 +126,17 @@ struct hexl_ks_plan {
     size_t cap = 0;
     hipStream_t aux[HX_KS_MAX_LANES] = {};
     hipEvent_t ev_start = nullptr, ev_done[HX_KS_MAX_LANES] = {};
-    u32* d_flag = nullptr;            // one device word + its pinned host mirror: input-range flag (HEXL_KS_VALIDATE)
+    u32* d_flag = nullptr;            // two device words + their pinned host mirrors: [0] the kernels' input-range flag (HEXL_W_RANGE), [1] HEXL_KS_VALIDATE's (HEXL_E_RANGE)
     u32* h_flag = nullptr;
     double* d_keys_nat = nullptr;     // N = 16384 FP64 plans: the keys as centred doubles in NATURAL order (latency path, keyswitch_lat.hip)
     bool x_skip = false;              // slot-major lazy kernels: moduli within LAZY_SKIP_MAX_RATIO of each other -> c_d and s' enter the
                                       // transforms without a range reduction (keyswitch_x.hip SKIP variants; HEXL_KSX_SKIP=0 turns it off)
     bool overwrite_result = false;    // host-pointer path, (b, d)-major FP64 kernels: write `result` instead of accumulating into it
+    // zero-copy lone keyswitch of the host-pointer entry point (capi.hip keyswitch_host_lone; set around ONE launch, else null):
+    // per-quarter-limb completion words and the range flag in pinned host memory (keyswitch_lat.hip KsArgsQ)
+    u32* host_done = nullptr;
+    u32* host_flag = nullptr;
+    u32 host_epoch = 0;
     hipStream_t cur = nullptr;        // stream the chunk being launched goes to
     u64* cur_scratch = nullptr;
 };

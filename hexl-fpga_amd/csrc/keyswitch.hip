@@ -458,18 +458,19 @@ __global__ void k_ks_validate(const u64* __restrict__ t, const u64* __restrict__
 }
 
 static int validate_inputs(hexl_ks_plan* p, const u64* d_result, const u64* d_t_target, size_t batch) {
-    // the plan's flag word and its pinned host mirror (allocated with the plan: nothing to allocate, free or leak per call, no
-    // asynchronous copy into pageable memory). It is shared with the kernels' own range flag and ORs into it: a violation an
-    // earlier launch on this plan has flagged and nobody has read yet (hexl_ks_range_check) is reported here as well instead
-    // of being wiped; the flag is left clean either way.
+    // HEXL_KS_VALIDATE has a flag word of its own beside the kernels' range flag (d_flag[1] / h_flag[1], allocated with the plan:
+    // nothing to allocate, free or leak per call, no asynchronous copy into pageable memory): HEXL_E_RANGE means "THIS call's inputs
+    // are out of range, nothing was computed". A violation an earlier launch on the plan has flagged in d_flag[0] and nobody has
+    // read yet stays there for hexl_ks_range_check / hexl_keyswitch_host (HEXL_W_RANGE) -- it is neither reported as a refusal of
+    // this, valid, call nor wiped (the shared word conflated the two statuses).
     // A call that WRITES its result (overwrite_result: the staging buffer of the host-pointer path is uninitialised on
     // purpose) has only t_target as input.
+    HX_CHECK(hipMemsetAsync(p->d_flag + 1, 0, sizeof(u32), p->ctx->stream));
     hipLaunchKernelGGL(k_ks_validate, dim3(2048), dim3(256), 0, p->ctx->stream, d_t_target, p->overwrite_result ? nullptr : d_result,
-                       p->d_mods, p->L, p->n, batch, p->d_flag);
-    HX_CHECK(hipMemcpyAsync(p->h_flag, p->d_flag, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
-    HX_CHECK(hipMemsetAsync(p->d_flag, 0, sizeof(u32), p->ctx->stream));
+                       p->d_mods, p->L, p->n, batch, p->d_flag + 1);
+    HX_CHECK(hipMemcpyAsync(p->h_flag + 1, p->d_flag + 1, sizeof(u32), hipMemcpyDeviceToHost, p->ctx->stream));
     HX_CHECK(hipStreamSynchronize(p->ctx->stream));
-    return *p->h_flag ? HEXL_E_RANGE : 0;
+    return p->h_flag[1] ? HEXL_E_RANGE : 0;
 }
 
 // the (b, d)-major FP64 kernels can write `result` instead of accumulating into it: every chunk of the batch must take them

@@ -47,6 +47,18 @@ struct KsArgsQ {
     u32 L, K;
     u32* range_flag;
     u32 overwrite, skip;     // as in keyswitch_f64.hip
+    // The host-pointer entry point runs a lone keyswitch ZERO-COPY (capi.hip keyswitch_host_lone, round 5): t_target and result are then
+    // device-visible PINNED HOST memory -- k_ksq_intt pulls the 0.8 MB of t_target across PCIe while it transforms (18.7 us against a
+    // 29.5 us hipMemcpyAsync in front of the kernel, tools/zero_copy_probe), k_ksq_down pushes its 1.6 MB the same way (31.6 against
+    // 43.2 us behind it). Hence: t_target is read exactly ONCE (k_ksq_intt leaves the raw words in `tcopy` for the slot == d terms of
+    // k_ksq_up), and k_ksq_down publishes every finished quarter limb in `done` so that the host can start adding limb by limb while
+    // the rest is still in flight.
+    u64* tcopy;              // [b][L][n] raw t_target words (device memory)
+    u32* done;               // pinned host words [b][2][L][4], written with `epoch` behind the quarter's result words; or null
+    u32* started;            // pinned host word: k_ksq_down's first workgroup writes `epoch` when it starts (the host then wakes its adders)
+    u32* gate;               // device word, zeroed by k_ksq_intt: quarter limbs of k_ksq_down published so far, or null = no ordering
+    u32 epoch;
+    u32 flag_on_host;        // range_flag is pinned host memory: report with a plain system-scope store, not an atomic OR
     unsigned long long tiermap;   // kernels built with LAZY = -1 (plans of mixed tiers): nibble i = reduction period of limb i (with_tier)
 };
 
@@ -127,6 +139,16 @@ __device__ __forceinline__ void forward_start(double (&a)[4], const double* w, c
     fwd_stages_f64<4, 0, 2, 1, 0, LAZY, true>(a, 0u, w, w, m);
 }
 
+// the input-range flag of a launch whose flag word may be pinned host memory: every reporter stores the same 1 (no read-modify-write
+// across PCIe, no dependence on PCIe AtomicOps)
+__device__ __forceinline__ void report_range_q(hxf::RangeMask bad, const KsArgsQ& a) {
+    if (a.flag_on_host) {
+        if (bad != 0 && (threadIdx.x & 63) == 0) __hip_atomic_store(a.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        hxf::report_range(bad, a.range_flag);
+    }
+}
+
 __device__ __forceinline__ u64 fold_below_q4(u64 x, u64 q) {     // x < 16 q -> x mod q
 #pragma unroll
     for (int s = 3; s >= 0; --s) { const u64 mq = q << s; x = x >= mq ? x - mq : x; }
@@ -144,14 +166,22 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_intt(KsArgsQ a) {
     for (u32 row = blockIdx.x; row < 2 * (L + 1) * 4; row += 4 * L)
 #pragma unroll
         for (int r = 0; r < GQ::E; ++r) (pb + size_t(row) * QM + GQ::idxA(r, 0))[u32(tid)] = 0;
+    if (a.gate && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.gate = 0;   // (k_ksq_down, three kernels later, counts in it)
     const KsModF64 md = a.mods[d];
     const u64 qd = (u64)md.m.p;
     const u64* src = a.t_target + (size_t(b) * L + d) * (1 << QLOGN) + size_t(q) * QM;
     double v[GQ::E];
     hxf::RangeMask bad = 0;
+    u64* keep = a.tcopy + (size_t(b) * L + d) * (1 << QLOGN) + size_t(q) * QM;
+    u64 raw[GQ::E];
 #pragma unroll
-    for (int r = 0; r < GQ::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + GQ::idxA(r, 0))[u32(tid)], qd, bad);   // canonical, as they are
-    hxf::report_range(bad, a.range_flag);
+    for (int r = 0; r < GQ::E; ++r) raw[r] = (src + GQ::idxA(r, 0))[u32(tid)];           // the only read of t_target (it may lie across PCIe)
+#pragma unroll
+    for (int r = 0; r < GQ::E; ++r) {
+        (keep + GQ::idxA(r, 0))[u32(tid)] = raw[r];
+        v[r] = hxf::to_f64_lt52_checked(raw[r], qd, bad);                                 // canonical, as they are
+    }
+    report_range_q(bad, a);
     a_to_b(v, ldsq, tid);
     const double* tb = a.tables + size_t(d) * 4 * (1 << QLOGN);
     with_tier<LAZY, false>(a.tiermap, d, [&](auto T) {
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_up(KsArgsQ a) {
         for (int r = 0; r < GQ::E; ++r) { ka[r] = (k0 + GQ::idxA(r, 0))[u32(tid)]; kb[r] = (k0 + N + GQ::idxA(r, 0))[u32(tid)]; }
     };
     if (slot == d) {                                              // NTT(INTT(t_d) mod q_d) = t_d
-        const u64* src = a.t_target + (size_t(b) * L + d) * N + size_t(q) * QM;
+        const u64* src = a.tcopy + (size_t(b) * L + d) * N + size_t(q) * QM;    // k_ksq_intt's copy of t_target[d]
         u64 raw[GQ::E];
 #pragma unroll
         for (int r = 0; r < GQ::E; ++r) raw[r] = (src + GQ::idxA(r, 0))[u32(tid)];
@@ -272,6 +302,8 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
     const double* tb = a.tables + size_t(i) * 4 * N;
     const unsigned long long* pi = a.prod + (size_t(b) * 2 * (L + 1) + k * (L + 1) + i) * N + size_t(q) * QM;
     u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * N + size_t(q) * QM;
+    if (a.done && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        __hip_atomic_store(a.started, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     u64 praw[GQ::E], old[GQ::E];
     double v[GQ::E];
     double sv[GQ::E][4];
@@ -310,6 +342,7 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
     b_to_a(v, ldsq, tid);
     const u64 qi = (u64)m.p;
     hxf::RangeMask bad = 0;
+    u64 outw[GQ::E];
 #pragma unroll
     for (int r = 0; r < GQ::E; ++r) {
         const double pv = hxf::reduce(hxf::to_f64_lt52(fold_below_q4(praw[r], qi)), m);
@@ -317,9 +350,31 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
         double rr;
         if (a.overwrite) rr = hxf::reduce(out, m);                                         // host-pointer path: the HOST adds
         else rr = hxf::reduce(hxf::to_f64_lt52_checked(old[r], qi, bad) + out, m);         // fpga.cpp:453-457
-        (res + GQ::idxA(r, 0))[u32(tid)] = hxf::from_f64(hxf::lift(rr, m));
+        outw[r] = hxf::from_f64(hxf::lift(rr, m));
     }
-    hxf::report_range(bad, a.range_flag);
+    // Zero-copy output (a.done): all 8 L workgroups finish their arithmetic at about the same time, and left alone their 1.6 MB of
+    // stores share the PCIe link evenly -- every limb would land at the very end. The gate lets the limbs through IN ORDER, about three
+    // at a time (enough bytes in flight to fill the link), so the host adds limb x into the caller's array while limbs x + 1 ... are
+    // still crossing. A workgroup only ever waits for lower-numbered ones, which were dispatched before it (the launcher only passes a
+    // gate for grids that are resident at once anyway).
+    const u32 limb = (b * 2 + k) * L + i;
+    if (a.gate && limb >= 3) {
+        if (tid == 0)
+            while (__hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (limb - 2)) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < GQ::E; ++r) (res + GQ::idxA(r, 0))[u32(tid)] = outw[r];
+    report_range_q(bad, a);
+    if (a.done) {
+        // this quarter of result[k][i] is complete: every thread's stores are released to the system scope, then ONE word says so
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(a.done + size_t(limb) * 4 + q, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.gate) __hip_atomic_fetch_add(a.gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,9 +423,14 @@ int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     double* prod = u + p->cap * (L + 1) * L * n;
     a.prod = reinterpret_cast<unsigned long long*>(prod);
     a.subsp = prod + p->cap * 2 * (L + 1) * n;
+    a.tcopy = reinterpret_cast<u64*>(u);                          // (the u region of the (b, d)-major layout is free on this path)
+    a.done = p->host_done; a.epoch = p->host_epoch;
+    a.started = p->host_done ? p->host_flag + 1 : nullptr;
+    a.gate = (p->host_done && nb * 8 * L <= 256) ? p->d_flag + 2 : nullptr;    // ordered output only while the whole grid is resident
+    a.flag_on_host = p->host_flag ? 1u : 0u;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K;
-    a.range_flag = p->d_flag;
+    a.range_flag = p->host_flag ? p->host_flag : p->d_flag;
     a.overwrite = p->overwrite_result ? 1u : 0u;
     a.skip = p->x_skip ? 1u : 0u;
     a.tiermap = 0;

@@ -65,33 +65,6 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     if (pd > hxf::LAZY_MAX_MODULUS) wp[i] = c / pd;                  // strict tier: the semi-strict forward schedule reads it
 }
 
-// The same verification and derivation INSIDE a persistent transform kernel (round 4: `violations == nullptr` asks for it), done by
-// every workgroup for itself -- all of them write the same values to the same table, each reads only behind its own writes and its own
-// barrier, so no grid-wide flag is needed: 16 entries per thread (~1 us, beside the first polynomial's load) instead of a 5.6 us kernel
-// in front of every launch. Returns true when some entry is not a Shoup pair. The caller must launder the table pointer behind this
-// call: the transforms read the table through the constant address space, and nothing else tells the compiler that those loads may not
-// be hoisted above the stores below.
-template <int N, int T>
-__device__ __forceinline__ bool tables_in_kernel(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q,
-                                                 double* __restrict__ w, double* __restrict__ wp) {
-    bool bad = false;
-    const double pd = (double)q;
-    const bool strict = pd > hxf::LAZY_MAX_MODULUS;
-#pragma unroll 4
-    for (u32 i = threadIdx.x; i < (u32)N; i += T) {
-        const u64 r = roots[i], p = precon[i];
-        const u64 lo = p * q, hi = mulhi(p, q);
-        const u64 d_lo = 0 - lo, d_hi = r - hi - (lo != 0);
-        const bool ok = (r < q) && (hi + (lo != 0) <= r) && (d_hi == 0) && (d_lo < q);
-        bad |= (i != 0) && !ok;                                  // index 0 is never read by either transform
-        const u64 rr = (i != 0 && r < q) ? r : 0;
-        const double c = rr > q / 2 ? (double)rr - pd : (double)rr;
-        w[i] = c;
-        if (strict) wp[i] = c / pd;
-    }
-    return __syncthreads_or(bad);     // barrier + workgroup-scope fence: the whole table is visible to every wave of this workgroup
-}
-
 // Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
 // FP64 code (inlined, the allocator spilled ~100 VGPRs on the fast path).
 template <int LOGN, int LOGE>
@@ -292,13 +265,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
-    bool bad_tables;
-    if (violations == nullptr) {                                  // no prepare kernel ran: this workgroup derives the table itself
-        bad_tables = tables_in_kernel<G::N, G::T>(roots, precon, q, const_cast<double*>(w), const_cast<double*>(wp));
-        asm volatile("" : "+s"(w), "+s"(wp));
-    } else {
-        bad_tables = *violations != 0;
-    }
+    const bool bad_tables = *violations != 0;                     // counted by k_ntt_prepare, which runs in front of every launch
     if (bad_tables) {
         // Tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones): known at kernel entry,
         // the same for every polynomial and wave-uniform -- the whole batch goes straight through the integer butterflies.
@@ -362,13 +329,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, false);
     const Mod m{(double)q, 1.0 / (double)q};
-    bool bad_tables;
-    if (violations == nullptr) {                                                // see k_ntt_fwd_p
-        bad_tables = tables_in_kernel<G::N, G::T>(iroots, iprecon, q, const_cast<double*>(w), const_cast<double*>(wp));
-        asm volatile("" : "+s"(w), "+s"(wp));
-    } else {
-        bad_tables = *violations != 0;
-    }
+    const bool bad_tables = *violations != 0;
     if (bad_tables) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
 #if !HX_NTT_NO_SLOW
@@ -427,16 +388,6 @@ static bool semi_enabled() {
     static const bool v = [] { const char* e = getenv("HEXL_NTT_SEMI"); return e && atoi(e) == 1; }();    // measured 2-4 % slower: off
     return v;
 }
-// HEXL_NTT_FUSED_PREPARE=1 (experiment, off): the persistent N = 16384 kernels verify and derive the table themselves, every workgroup
-// for itself (tables_in_kernel), instead of the separate k_ntt_prepare launch; a hinted table set (NttHint) keeps the prepare kernel,
-// whose counter clears the hint. Bit-exact (tests/test_gpu_ntt.py incl. tables edited in place), measured SLOWER: 12.2 M against
-// 12.9-13.2 M forward NTT/s at batch 1024, 14.1 M against 14.3-14.6 M at batch 4096 -- sixteen 64-bit Shoup checks and conversions per
-// thread are half a transform's worth of instructions per launch, more than the 5.6 us kernel they replace.
-static bool prepare_in_kernel(const hexl_ctx* ctx, int logn, size_t batch, bool hinted) {
-    static const bool on = [] { const char* e = getenv("HEXL_NTT_FUSED_PREPARE"); return e && atoi(e) == 1; }();
-    static const bool persist = [] { const char* e = getenv("HEXL_NTT_PERSIST"); return !(e && atoi(e) == 0); }();
-    return on && persist && !hinted && logn == 14 && batch > (size_t)ctx->num_cu;
-}
 static bool fast_path_enabled() {
     static const bool v = [] { const char* e = getenv("HEXL_NTT_INT"); return !(e && atoi(e) == 1); }();
     return v;
@@ -453,7 +404,7 @@ static int ensure_ntt_hint(hexl_ctx* ctx) {                        // NttHint: f
 
 // device scratch for the derived tables: [w | w/p] (n doubles each) + the violation counter
 static int prepare_tables(hexl_ctx* ctx, const u64* roots, const u64* precon, u64 q, u64 n, double** w, double** wp,
-                          u32** viol, bool in_kernel = false) {
+                          u32** viol) {
     // layout: 64 violation counters (one per launch, round robin: no memset per launch -- each launch's prepare kernel
     // zeroes the counter 32 launches ahead, long after its last reader has finished on this stream), then w, w/p
     const size_t bytes = 256 + 2 * n * sizeof(double);
@@ -465,7 +416,6 @@ static int prepare_tables(hexl_ctx* ctx, const u64* roots, const u64* precon, u6
     *w = (double*)((char*)ctx->d_ntt_tab + 256);
     *wp = *w + n;
     if (int rch = ensure_ntt_hint(ctx)) return rch;
-    if (in_kernel) { *viol = nullptr; return 0; }                  // the persistent transform kernel prepares the table itself
     const u32 seq = ctx->ntt_seq++;
     *viol = counters + (seq & 63);
     hipLaunchKernelGGL(k_ntt_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, roots, precon, q,
@@ -801,7 +751,7 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
         // once the prepare kernel (still run for a hinted set) finds the tables genuine
         if (int rch = ensure_ntt_hint(ctx)) return rch;
         const bool hinted = ntt_hinted(ctx, roots, precon, q, n, 0);
-        int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol, prepare_in_kernel(ctx, logn, batch, hinted));
+        int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol);
         if (rc) return rc;
         if (hinted) ctx->ntt_clear_viol = viol;
         const int period = hxf::lazy_period_for((double)q);       // fewer range reductions for smaller moduli (N = 16384)
@@ -838,7 +788,7 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
         double *w, *wp; u32* viol;
         if (int rch = ensure_ntt_hint(ctx)) return rch;
         const bool hinted = ntt_hinted(ctx, ir, ip, q, n, 1);     // see hx_launch_ntt_fwd
-        int rc = prepare_tables(ctx, ir, ip, q, n, &w, &wp, &viol, prepare_in_kernel(ctx, logn, batch, hinted));
+        int rc = prepare_tables(ctx, ir, ip, q, n, &w, &wp, &viol);
         if (rc) return rc;
         if (hinted) ctx->ntt_clear_viol = viol;
         const double pd = (double)q;

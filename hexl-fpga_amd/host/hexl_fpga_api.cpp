@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,15 @@ namespace {
 unsigned long env_ul(const char* name, unsigned long dflt) {
     const char* e = std::getenv(name);
     return e ? std::strtoul(e, nullptr, 10) : dflt;
+}
+
+// HEXL_HOST_TRACE=1: microseconds (steady clock, since the process's first stamp) at the hand-over points of a call, on stderr
+bool host_trace() { static const bool on = env_ul("HEXL_HOST_TRACE", 0) == 1; return on; }
+void trace_stamp(const char* what) {
+    if (!host_trace()) return;
+    // (absolute steady-clock microseconds modulo 10^8: the same time base as the staging pipeline's stamps in libhexl_mi355x.so)
+    std::fprintf(stderr, "[hexl api ] %-28s @%12.1f us\n", what,
+                 std::fmod(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1e8));
 }
 
 enum Kind { DY = 0, KS = 1, NTT = 2, INTT = 3, NKIND = 4 };
@@ -285,7 +295,9 @@ void runner_loop(Engine* ep, size_t di) {
                          kind_name[run.front().kind], (unsigned long)run.front().n, e.fifo.size());
         lk.unlock();
         if (nd > 1) e.cv_work.notify_all();                       // the rest of the run is for the other runners
+        trace_stamp("runner: run taken");
         execute(e, dev, run);
+        trace_stamp("runner: run executed");
         lk.lock();
         for (const Obj& o : run) {
             auto it = e.inflight_out.find(o.out);
@@ -311,7 +323,11 @@ void submit(Engine& e, Obj o) {
     e.fifo.push_back(o);
     if (e.window_open[o.kind]) --e.window_open[o.kind];
     e.cv_work.notify_all();
-    if (e.ws[o.kind] == 1) e.cv_done.wait(lk, [&] { return e.retired[o.kind] >= mine; });
+    if (e.ws[o.kind] == 1) {
+        trace_stamp("caller: submitted, waiting");
+        e.cv_done.wait(lk, [&] { return e.retired[o.kind] >= mine; });
+        trace_stamp("caller: woken");
+    }
 }
 
 bool completed(Kind k) {
@@ -413,6 +429,7 @@ void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n, 
             "KeySwitch: requires decomp_modulus_size < key_modulus_size <= 16");            // reference: <= 7
     Engine& e = eng();
     int plan;
+    trace_stamp("caller: KeySwitch entered");
     for (uint64_t d = 0; d < decomp_modulus_size; ++d) REQUIRE(k_switch_keys[d], "KeySwitch: null key pointer");
     const uint64_t fp = key_fingerprint(k_switch_keys, decomp_modulus_size, key_modulus_size, n);
     {

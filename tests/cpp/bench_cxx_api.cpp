@@ -1,13 +1,14 @@
 // bench_cxx_api.cpp -- end-to-end (host pointers, PCIe included) throughput of the reference's public C++ API on
 // libhexl-fpga.so, shaped like benchmark/bench_keyswitch.cpp:113-131 and bench_fwd_ntt.cpp:46-62: one warm-up
 // window, then timed worksize windows. Synthetic in-range data (splitmix). Prints keyswitch/s and NTT/s.
-//   usage: bench_cxx_api [worksize = 256] [L = 6] [ntt = 1|0] [json = 0|1]
+//   usage: bench_cxx_api [worksize = 256] [L = 6] [ntt = 1|0] [json = 0|1] [chain = 52bit|seal]
 // json = 1 prints one JSON object instead (bench.py's `extra.cxx_api_end_to_end` leg: SURVEY 8d's end-to-end measurement at the
 // batch sizes of benchmark/micro_keyswitch.sh -- these rates include PCIe and the host copies and are never `value`).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../include/hexl-fpga.h"
@@ -21,12 +22,17 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char** argv) {
     const size_t batch = argc > 1 ? atoi(argv[1]) : 256;
-    const uint64_t n = 16384, L = argc > 2 ? atoi(argv[2]) : 6, K = L + 1;
     const bool with_ntt = argc > 3 ? atoi(argv[3]) != 0 : true, json = argc > 4 && atoi(argv[4]) == 1;
+    // chain = "seal": bridge-seal's prime chain (experimental/bridge-seal/tests/seal_test.sh:20: 52,30,30,40,27,27,27 bits -- the largest
+    // primes = 1 mod 2n of each size, as SEAL's CoeffModulus::Create picks them), 7 key moduli whatever L: L = 6 is its relinearisation,
+    // L = 5 the rotation behind the rescale
+    const bool seal = argc > 5 && std::string(argv[5]) == "seal";
+    const uint64_t n = 16384, L = argc > 2 ? atoi(argv[2]) : 6, K = seal ? 7 : L + 1;
     // the eight 52-bit primes of SURVEY 8c (GeneratePrimes(8, 51, 16384))
     const uint64_t primes[8] = {2251799814045697ull, 2251799814799361ull, 2251799814930433ull, 2251799815094273ull,
                                 2251799815487489ull, 2251799815520257ull, 2251799816273921ull, 2251799816568833ull};
-    vec moduli(primes, primes + K), msf(K, 12345);
+    const uint64_t seal_primes[7] = {4503599626682369ull, 1073643521ull, 1073479681ull, 1099510054913ull, 133857281ull, 132710401ull, 132612097ull};
+    vec moduli(seal ? seal_primes : primes, (seal ? seal_primes : primes) + K), msf(K, 12345);
     std::vector<vec> keys(L, vec(2 * K * n));
     for (auto& k : keys) for (uint64_t kk = 0; kk < 2; ++kk) for (uint64_t i = 0; i < K; ++i) for (uint64_t j = 0; j < n; ++j) k[(kk * K + i) * n + j] = sm() % moduli[i];
     std::vector<const uint64_t*> kp; for (auto& k : keys) kp.push_back(k.data());
@@ -38,7 +44,7 @@ int main(int argc, char** argv) {
     acquire_FPGA_resources();
     auto window = [&]() {
         set_worksize_KeySwitch(batch);
-        for (size_t b = 0; b < batch; ++b) KeySwitch(r[b].data(), t[b].data(), n, L, K, L + 1, 2, moduli.data(), kp.data(), msf.data());
+        for (size_t b = 0; b < batch; ++b) KeySwitch(r[b].data(), t[b].data(), n, L, K, K, 2, moduli.data(), kp.data(), msf.data());
         KeySwitchCompleted();
     };
     window();

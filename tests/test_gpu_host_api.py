@@ -165,3 +165,56 @@ def test_device_pointers_dyadic(hx, ctx, dev, orc):
     got = hx.to_u64(d_o)
     for i in range(num):
         assert np.array_equal(got[i], orc.dyadic(a[i], b[i], n, mod))
+
+
+@pytest.mark.parametrize("env", [{}, {"HEXL_HOST_ZERO_COPY": "0"}], ids=["zero_copy", "staged"])
+def test_lone_keyswitch_through_the_host_entry_point(env):
+    """hexl_keyswitch_host at the SEAL bridge's worksize 1 (fpga_context.h:13-16). Round 5: the quarter-transform kernels read t_target from
+    and write their output to PINNED HOST memory themselves, publish every quarter limb, and the host adds limb by limb while the rest is in
+    flight (capi.hip keyswitch_host_lone); HEXL_HOST_ZERO_COPY=0 keeps the staged route. Same bits as the oracle either way: repeated calls
+    (the pinned slabs and completion words are reused), accumulation into the caller's array, two and three objects per call, objects that
+    ALIAS one result array (added in order), the 52-bit chain and bridge-seal's mixed one, and L = 7."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+from ks_util import KsCase, seal_chain
+ctx = hx.Context(0)
+n = 16384
+for L, K, moduli in ((6, 7, None), (5, 7, seal_chain(orc, 7, n)), (7, 8, None)):
+    case = KsCase(orc, n, L, K, seed=61, moduli=moduli)
+    plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
+    ins = [case.inputs(orc, b) for b in range(3)]
+    for rep in range(4):                                          # one object per call, again and again
+        t, r = ins[rep %% 3]
+        got = r.copy()
+        assert plan.keyswitch_host([got], [t]) is True
+        want = case.expected(orc, t, r)
+        assert np.array_equal(got, want), ("lone", L, rep)
+        assert plan.keyswitch_host([got], [t]) is True            # accumulates into what the first call left
+        assert np.array_equal(got, case.expected(orc, t, want)), ("accumulate", L, rep)
+    outs = [r.copy() for _, r in ins]
+    assert plan.keyswitch_host(outs[:2], [t for t, _ in ins[:2]]) is True
+    for b in range(2):
+        assert np.array_equal(outs[b], case.expected(orc, *ins[b])), ("two objects", L, b)
+    if L < 7:                                                     # three objects at L = 7 exceed the quarter-transform path's default
+        shared = ins[0][1].copy()                                 # three objects, ONE result array: added in submission order
+        assert plan.keyswitch_host([shared, shared, shared], [t for t, _ in ins]) is True
+        want = ins[0][1].copy()
+        for t, _ in ins:
+            want = case.expected(orc, t, want)
+        assert np.array_equal(shared, want), ("aliased", L)
+    bad = ins[0][0].copy(); bad[n + 3] = case.moduli[1]           # limb 1, a word equal to its modulus: reported, not fatal
+    assert plan.keyswitch_host([ins[0][1].copy()], [bad]) is False
+    assert plan.keyswitch_host([ins[0][1].copy()], [ins[0][0]]) is True
+    plan.close()
+print("OK")
+''' % (str(root), str(root / "oracle"), str(root / "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    print(out.stdout[-800:], out.stderr[-2000:])
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK")

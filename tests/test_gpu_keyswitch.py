@@ -374,6 +374,15 @@ def test_host_pointer_range_status_covers_its_own_call(hx, ctx, dev, orc):
     assert np.array_equal(g1, case.expected(orc, t1, r1))
     got = r.copy()
     assert plan.keyswitch_host([got], [t]) is True
+    # the same entry point on DEVICE pointers (the zero-copy branch): a stale flag of an earlier launch is not this call's status either
+    # (only the staged branch cleared it), a dirty object of the call itself is
+    plan.keyswitch(hx.as_i64(r).to(dev), hx.as_i64(bad).to(dev), 1)
+    ctx.sync()
+    d_t, d_r = hx.as_i64(t).to(dev), hx.as_i64(r).to(dev)
+    assert plan.keyswitch_host([d_r], [d_t]) is True
+    assert np.array_equal(hx.to_u64(d_r), case.expected(orc, t, r))
+    assert plan.keyswitch_host([hx.as_i64(r).to(dev)], [hx.as_i64(bad).to(dev)]) is False
+    assert plan.keyswitch_host([hx.as_i64(r).to(dev)], [d_t]) is True
     plan.close()
 
 
