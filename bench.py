@@ -361,6 +361,53 @@ class PowerSampler:
                 "source": self.dir}
 
 
+def ntt_roofline_block(timed, pmc_ntt, cus, timed_sclk_mhz=None):
+    """BASELINE's second metric (fwd / inv NTT per second, N = 16384, batch 1024) against both of ITS bounds, like the keyswitch's block:
+    `frac` = algorithmic bytes (262,144 B per transform) per launch / the timed launch duration / 8 TB/s; `traffic` = L2-miss-side
+    bytes per launch from the in-run PMC passes (transform kernel + the table-preparation kernel in front of it); `alu` = the FP64-issue
+    bound -- VALU wave-instructions per launch x 4 cycles / SIMDs / clock against the timed launch (at the timed region's own shader clock
+    when hwmon gave one, else the counter passes' clock, labelled)."""
+    out = {}
+    for leg in ("fwd", "inv"):
+        t = timed.get(leg)
+        if not t:
+            continue
+        batch = 1024
+        us = t["ms_per_launch"] * 1e3
+        alg = batch * 2 * N * 8
+        b = {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg, "timed_us_per_launch": us,
+             "frac_of_measured_copy_ceiling_6290_GBps": alg / (us * 1e-6) / 1e9 / 6290.0, "traffic": None}
+        p = (pmc_ntt or {}).get(leg)
+        if p:
+            b["traffic"] = p.get("traffic_bytes_per_launch")
+            b["traffic_over_algorithmic"] = p.get("traffic_over_algorithmic")
+            b["traffic_kind"] = "L2-miss side (2 x FETCH_SIZE + WRITE_SIZE), transform kernel + k_ntt_prepare, in-run PMC passes"
+            vw = p.get("valu_wave_instructions_per_launch")
+            if vw:
+                ghz = (timed_sclk_mhz / 1e3) if timed_sclk_mhz else p.get("shader_clock_ghz")
+                issue_us = vw * 4.0 / (4 * cus) / (ghz * 1e3) if ghz else None
+                b["alu"] = {"bound": "valu_fp64", "valu_wave_instructions_per_launch": vw,
+                            "valu_wave_instructions_per_transform": p.get("valu_wave_instructions_per_transform"),
+                            "shader_clock_ghz": ghz, "shader_clock_source": "hwmon over the timed NTT launches" if timed_sclk_mhz else "PMC passes (GRBM_GUI_ACTIVE of k_ksx_main)",
+                            "issue_us_per_launch": issue_us, "achieved_frac": issue_us / us if issue_us else None,
+                            "under_pmc": {k: p.get(k) for k in ("avg_us_under_pmc", "prepare_kernel_avg_us_under_pmc", "fp64_issue_frac_under_pmc", "wave_time_split")}}
+        out[leg] = b
+    return out
+
+
+def key_stream_split(traffic_per_ks, traffic_per_ks_keys_aliased):
+    """The key stream's share of the L2-miss-side bytes per keyswitch = (the real pipeline) - (every key row reading row 0), BOTH measured
+    on the shipped library's kernel objects (the key-alias variant differs in one launcher function only). What is left -- c and s'
+    written once and re-read from another XCD's L2, t_target, the result read-modify-write, the twiddle tables -- is the DRAM-side
+    estimate: the 14.7 MB key set lives in the 256 MiB Infinity Cache."""
+    return {"key_stream_bytes_per_keyswitch": traffic_per_ks - traffic_per_ks_keys_aliased,
+            "dram_side_estimate_bytes_per_keyswitch": traffic_per_ks_keys_aliased,
+            "dram_side_estimate_note": "L2-miss-side bytes (2 x FETCH_SIZE + WRITE_SIZE) of the same passes with every key row aliased onto row 0 "
+                                       "(HEXL_KSX_ALIAS=1 on libhexl_mi355x_keyalias.so: the shipped kernel objects, one launcher function differs): "
+                                       "the key stream (L2 misses served by the Infinity Cache) removed"}
+
+
 def alu_block(valu_per_ks, cus, measured_us_per_ks, timed_sclk_mhz, pmc_clock_ghz):
     """The FP64-issue bound, self-consistent: instructions per keyswitch x 4 cycles / SIMDs / CLOCK against the measured time per
     keyswitch OF THE TIMED REGION -- so the clock must be the timed region's own (hwmon samples of the shader clock while it ran),
@@ -394,9 +441,12 @@ def pmc_inrun(L, cus, timeout_s=90):
     """The roofline block's counter inputs measured INSIDE this benchmark run: rocprofv3 PMC passes (one counter group per
     run, --kernel-trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE and WRITE_SIZE in their own passes) of the native
     workload tools/pmc_workload (2 launches of a 256-keyswitch chunk, same library, same kernels), plus two passes of the
-    PROFILING build (tools/pmc_workload_prof on lib/libhexl_mi355x_prof.so) with every key row aliased onto row 0
-    (HEXL_KSX_ALIAS=1; the shipped library has no such knob): the difference is the key stream's share of the L2-miss-side bytes,
-    which the 256 MiB Infinity Cache serves (the key set is 14.7 MB), so what is left estimates the DRAM side.
+    KEY-ALIAS variant (tools/pmc_workload_keyalias on lib/libhexl_mi355x_keyalias.so: the shipped library's own kernel OBJECTS, only
+    the launcher lets HEXL_KSX_ALIAS=1 point every key row at row 0; the shipped library has no such knob): the difference is the key
+    stream's share of the L2-miss-side bytes, which the 256 MiB Infinity Cache serves (the key set is 14.7 MB), so what is left
+    estimates the DRAM side. (Rounds 3-4 took the aliased passes from the PROFILING build, whose kernels spill more and move 19.2 MB
+    per keyswitch where the shipped ones move 14.4: a difference ACROSS the builds, 0.6-0.7 MB where 5 MB is right --
+    profiles/r05_fetch_reconcile.json, tools/fetch_reconcile.py.)
     Returns (derived dict, None) or (None, reason)."""
     import shutil
     import subprocess
@@ -417,20 +467,25 @@ def pmc_inrun(L, cus, timeout_s=90):
 
     def passes(root, groups, extra_env, exe=exe):
         for i, g in enumerate(groups):
-            cmd = [rocprof, "--kernel-trace", "--pmc", *g.split(), "-d", f"{root}/p{i + 1}", "--", str(exe), str(PMC_BATCH), str(L), "2"]
+            # (... 2 1: two launches of the keyswitch chunk, then two forward + inverse NTT launches of 1024 polynomials: BASELINE's second
+            # metric gets its counters from the same passes)
+            cmd = [rocprof, "--kernel-trace", "--pmc", *g.split(), "-d", f"{root}/p{i + 1}", "--", str(exe), str(PMC_BATCH), str(L), "2", "1"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(env, **extra_env), timeout=timeout_s, capture_output=True, text=True)
             if r.returncode:
                 raise RuntimeError(f"rocprofv3 pass '{g}' exited {r.returncode}: {r.stderr[-300:]}")
         vals, dur = pmc_summary.collect(root)
-        return pmc_summary.derive(vals, dur, PMC_BATCH, L, simds=4 * cus)
+        d = pmc_summary.derive(vals, dur, PMC_BATCH, L, simds=4 * cus)
+        d["ntt"] = pmc_summary.derive_ntt(vals, dur, 1024, simds=4 * cus, clock_ghz=d.get("shader_clock_ghz"))
+        return d
     try:
         with tempfile.TemporaryDirectory(prefix="hexl_pmc_", dir="/tmp") as tmp:
             d = passes(tmp + "/a", groups, {})
             if d["traffic_bytes_per_keyswitch"] is None or d["valu_wave_instructions_per_keyswitch"] is None:
                 return None, "PMC passes returned no counters for the keyswitch kernels"
             try:
-                al = passes(tmp + "/b", ["FETCH_SIZE", "WRITE_SIZE"], {"HEXL_KSX_ALIAS": "1"}, ROOT / "tools" / "pmc_workload_prof")
+                al = passes(tmp + "/b", ["FETCH_SIZE", "WRITE_SIZE"], {"HEXL_KSX_ALIAS": "1"}, ROOT / "tools" / "pmc_workload_keyalias")
                 d["traffic_bytes_per_keyswitch_keys_aliased"] = al["traffic_bytes_per_keyswitch"]
+                d["keys_aliased_kernels"] = "byte-identical to the shipped library's (libhexl_mi355x_keyalias.so links the same objects)"
             except Exception as e:                                  # the estimate is optional
                 d["traffic_bytes_per_keyswitch_keys_aliased"] = None
                 d["keys_aliased_error"] = str(e)[:200]
@@ -579,7 +634,15 @@ def main():
     }
     # BASELINE's second metric, fwd-NTT/sec at N=16384 at 1/2/4/8 GPUs: config 2's shape on every rank, whole-job rate
     # (300 launches per leg, ~25 ms: ten launches end before the clocks and the power limit have settled and read 8 % low)
-    ntt = None if a.no_extra else time_ntt(hx, ctx, orc_mod, dev, 1024, 300, barrier, slowest, world)
+    ntt_power = None
+    if a.no_extra:
+        ntt = None
+    else:
+        ntt_sampler = PowerSampler(local) if rank == 0 else None
+        if ntt_sampler:
+            ntt_sampler.start()
+        ntt = time_ntt(hx, ctx, orc_mod, dev, 1024, 300, barrier, slowest, world)
+        ntt_power = ntt_sampler.stop() if ntt_sampler else None
     if rank == 0:
         alg = ks_alg_bytes(N, L)
         ach = alg * mine * a.steps / (dev_ms * 1e-3) / 1e9            # this rank, device-timed
@@ -604,10 +667,7 @@ def main():
             if al:
                 # written once (c, s'), compulsory, or re-read from another XCD: everything except the key rows, which come out of the
                 # Infinity Cache (14.7 MB key set against 256 MiB)
-                traffic_extra = {"key_stream_bytes_per_keyswitch": pmc["traffic_bytes_per_keyswitch"] - al,
-                                 "dram_side_estimate_bytes_per_keyswitch": al,
-                                 "dram_side_estimate_note": "L2-miss-side bytes of the same passes on the profiling build with every key row aliased onto row 0 "
-                                                            "(HEXL_KSX_ALIAS=1): the key stream (L2 misses served by the Infinity Cache) removed"}
+                traffic_extra = key_stream_split(pmc["traffic_bytes_per_keyswitch"], al)
             per_kernel = {k: {kk: e.get(kk) for kk in ("avg_us_under_pmc", "fp64_issue_frac", "wave_time_split", "read_bytes", "write_bytes")}
                           for k, e in pmc["kernels"].items()}
         else:
@@ -653,6 +713,11 @@ def main():
             out["ntt_fwd_per_s"] = ntt["fwd"]["ntt_per_s_all_ranks"]
             out["ntt_inv_per_s"] = ntt["inv"]["ntt_per_s_all_ranks"]
             out["ntt_config"] = f"N={N}, q={ntt['q']} (51-bit, exact FP64 fast path), batch 1024 per GPU per launch, {world} GPU(s)"
+            # ... and its own roofline block (round 5): HBM fraction from the timed launches, L2-miss-side traffic and the FP64-issue
+            # fraction from the same in-run PMC passes as the keyswitch's
+            out["ntt_roofline"] = ntt_roofline_block(ntt, (pmc or {}).get("ntt"), cus, (ntt_power or {}).get("sclk_mhz_mean"))
+            if ntt_power:
+                out["ntt_roofline"]["power"] = ntt_power
         if not a.no_extra and world == 1:
             extra["ntt_N16384_batch4096"] = time_ntt(hx, ctx, orc_mod, dev, 4096, 100)      # launch overhead amortised over 4x the work
             # the slower standalone-NTT paths, same shape: SURVEY 8d's own prime (2^52 + 393217 is above the LAZY FP64 range: strict

@@ -996,9 +996,14 @@ bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
     return pipe == 3 || (pipe == 2 && ((4 * nb * p->L) << p->logn) >= ((7 * (size_t)p->ctx->num_cu) << 14));  // 3: always (tests)
 }
 
-// the plan's alias mask (profiling builds only; the shipped library ignores the variables)
-static u32 ksx_alias_mask() {
+// The plan's alias mask. Profiling builds (-DHEXL_PROFILING_AIDS: every stream, KX_ALIASED compiled into the kernels) read it from the
+// environment here. Everywhere else it comes from hx_ksx_alias_mask() in alias_knob.hip -- a constant 0 in the shipped library. Aliasing
+// the KEY rows needs no kernel support at all (key_stride is a launch argument), so libhexl_mi355x_keyalias.so links these very objects
+// with a variant of that one function that honours bit 1: the key stream can then be taken out of the counters on kernels that are
+// byte-identical to the shipped ones (round 5: the profiling build spills more and moves 19.2 MB per keyswitch where the shipped kernels
+// move 14.4 -- differences taken ACROSS the two builds were wrong, profiles/r05_fetch_reconcile.json).
 #ifdef HEXL_PROFILING_AIDS
+static u32 ksx_alias_mask() {
     static const u32 mask = [] {
         const char *e = getenv("HEXL_KSX_ALIAS"), *k = getenv("HEXL_KSX_KEY_ALIAS");
         const u32 m = (e ? (u32)atoi(e) : 0u) | ((k && atoi(k) == 1) ? 1u : 0u);
@@ -1006,10 +1011,11 @@ static u32 ksx_alias_mask() {
         return m;
     }();
     return mask;
-#else
-    return 0u;
-#endif
 }
+#else
+u32 hx_ksx_alias_mask();
+static u32 ksx_alias_mask() { return hx_ksx_alias_mask(); }
+#endif
 
 int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
                           hipEvent_t* ev) {

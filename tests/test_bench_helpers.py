@@ -102,3 +102,45 @@ def test_gpus_flag_is_never_silently_ignored(monkeypatch):
             raise AssertionError("must refuse")
         except SystemExit as e:
             assert "WORLD_SIZE" in str(e.code) and "refusing" in str(e.code)
+
+
+def test_key_stream_split_is_a_same_kernel_difference():
+    """roofline.key_stream_bytes_per_keyswitch = L2-miss-side bytes of the real pipeline minus those with every key row aliased onto row 0,
+    both on the SHIPPED kernel objects (round 5; rounds 3-4 subtracted a pass of the profiling build, whose kernels move 19.2 MB per
+    keyswitch where the shipped ones move 14.4, and printed 0.7 MB where ~5 MB is right). The arithmetic, on profiles/r05_fetch_reconcile's
+    numbers; and the key-alias library must be made of the shipped objects plus ONE other translation unit."""
+    import bench
+    d = bench.key_stream_split(14.43e6, 9.41e6)
+    assert abs(d["key_stream_bytes_per_keyswitch"] - 5.02e6) < 1 and d["dram_side_estimate_bytes_per_keyswitch"] == 9.41e6
+    mk = (ROOT / "hexl-fpga_amd" / "csrc" / "Makefile").read_text()
+    assert "libhexl_mi355x_keyalias.so: $(KOBJS) $(OUT)/alias_knob_keys.o" in mk and "OBJS     = $(KOBJS) $(OUT)/alias_knob.o" in mk
+    knob = (ROOT / "hexl-fpga_amd" / "csrc" / "alias_knob.hip").read_text()
+    assert "#ifdef HEXL_KEY_ALIAS_KNOB" in knob and "return 0u;" in knob          # the shipped variant reads no environment variable
+    assert "getenv" not in knob.split("#else")[1]
+
+
+def test_ntt_roofline_block_arithmetic():
+    """BASELINE's second metric gets its own roofline block (round 5): HBM fraction from the timed launch, traffic and the FP64-issue
+    fraction from the in-run PMC passes (transform kernel + k_ntt_prepare)."""
+    import bench
+    import pmc_summary
+    vals = {"k_ntt_fwd_p<14, 4, 3, false>": {"SQ_INSTS_VALU": 2.3e7, "FETCH_SIZE": 70000.0, "WRITE_SIZE": 131072.0,
+                                             "SQ_WAVE_CYCLES": 1.0e9, "SQ_ACTIVE_INST_ANY": 2.2e8, "SQ_WAIT_INST_ANY": 4.1e8, "SQ_WAIT_ANY": 3.7e8},
+            "k_ntt_inv_p<14, 4, 3, false>": {"SQ_INSTS_VALU": 2.5e7, "FETCH_SIZE": 70000.0, "WRITE_SIZE": 131072.0},
+            "k_ntt_prepare": {"SQ_INSTS_VALU": 1.0e5, "FETCH_SIZE": 128.0, "WRITE_SIZE": 128.0},
+            "k_ksx_main<14, 4, 3, false, true, false>": {"SQ_INSTS_VALU": 3.6e8}}
+    dur = {"k_ntt_fwd_p<14, 4, 3, false>": [72.0, 74.0], "k_ntt_inv_p<14, 4, 3, false>": [70.0], "k_ntt_prepare": [3.0], "k_ksx_main<14, 4, 3, false, true, false>": [1000.0]}
+    d = pmc_summary.derive_ntt(vals, dur, 1024, simds=1024, clock_ghz=2.0)
+    f = d["fwd"]
+    assert f["alg_bytes_per_launch"] == 1024 * 262144                                  # SURVEY 8d: 262,144 B per transform
+    assert f["read_bytes_per_launch"] == (70000.0 + 128.0) * 1024 * 2 and f["write_bytes_per_launch"] == (131072.0 + 128.0) * 1024
+    assert abs(f["traffic_over_algorithmic"] - (f["read_bytes_per_launch"] + f["write_bytes_per_launch"]) / (1024 * 262144)) < 1e-12
+    assert f["valu_wave_instructions_per_transform"] == 2.3e7 / 1024
+    assert abs(f["fp64_issue_frac_under_pmc"] - 2.3e7 * 4 / 1024 / 2000.0 / 73.0) < 1e-12     # 4 cycles per wave64 FP64 instruction per SIMD
+    timed = {"fwd": {"ms_per_launch": 0.0768}, "inv": {"ms_per_launch": 0.0765}}
+    b = bench.ntt_roofline_block(timed, d, cus=256, timed_sclk_mhz=2100.0)
+    assert abs(b["fwd"]["achieved"] - 1024 * 262144 / 76.8e-6 / 1e9) < 1e-6 and abs(b["fwd"]["frac"] - b["fwd"]["achieved"] / 8000.0) < 1e-12
+    assert abs(b["fwd"]["alu"]["issue_us_per_launch"] - (2.3e7 + 1.0e5) * 4 / 1024 / 2100.0) < 1e-9
+    assert abs(b["fwd"]["alu"]["achieved_frac"] - b["fwd"]["alu"]["issue_us_per_launch"] / 76.8) < 1e-12
+    assert b["fwd"]["traffic"] == f["traffic_bytes_per_launch"] and b["inv"]["alu"]["shader_clock_source"].startswith("hwmon")
+    assert bench.ntt_roofline_block(timed, None, 256)["fwd"]["traffic"] is None              # --no-pmc: the HBM fraction alone

@@ -14,7 +14,7 @@ Runs on the GPU box (rocprofv3 + the profiling build of the library):
      what the throughput and the energy per keyswitch do then is that stream's share of the watts.
   3. a calibration of bytes per TCP_TCC_READ_REQ / TCC_REQ on a known byte count (tools/fetch_calib: 1 GiB per kernel, cache-cold).
 
-Writes <out>/r04_bytes.json (default gpurun_out/bytes/) -- copy to profiles/r04_bytes.json.
+Writes <out>/r05_bytes.json (default gpurun_out/bytes/) -- copy to profiles/r05_bytes.json.
 
     python tools/byte_budget.py [--out DIR] [--L 7] [--power-seconds 8] [--masks 0,1,2,4,8,16,31]
 """
@@ -109,10 +109,20 @@ def main():
     res["bytes_per_request"] = {"TCP_TCC_READ_REQ": b_tcp_rd, "TCP_TCC_WRITE_REQ": b_tcp_wr, "TCC_REQ": b_tcc,
                                 "note": "1 GiB / requests of the 8-byte-per-lane coalesced calibration kernels; 64 / 64 / 128 assumed where a pass failed"}
 
-    for m in masks:
-        env = dict(env0, HEXL_KSX_ALIAS=str(m))
-        e = {"stream_aliased": STREAM.get(m, f"mask {m}"), "per_kernel": {}}
-        groups = ["tcp", "tcc", "fetch", "write"] + (["sq"] if m == 0 else [])
+    # round 5: the PROFILING build's kernels are not the shipped ones (KX_ALIASED in the address arithmetic: more spills -- 19.2 MB per
+    # keyswitch at mask 0 where the shipped kernels move 14.4, tools/fetch_reconcile.py), so its ABSOLUTE totals overstate the shipped
+    # pipeline; differences between its masks remain that build's stream shares. Two more legs on the SHIPPED kernel objects give the
+    # absolute figures and the key stream's share there: "shipped" (tools/pmc_workload) and "shipped_keys" (tools/pmc_workload_keyalias,
+    # HEXL_KSX_ALIAS=1: every key row reads row 0; libhexl_mi355x_keyalias.so links the shipped objects).
+    legs = [(str(m), exe, {"HEXL_KSX_ALIAS": str(m)}, STREAM.get(m, f"mask {m}") + " [profiling build]") for m in masks]
+    legs += [("shipped", ROOT / "tools" / "pmc_workload", {}, "none (the real pipeline) [SHIPPED kernels]"),
+             ("shipped_keys", ROOT / "tools" / "pmc_workload_keyalias", {"HEXL_KSX_ALIAS": "1"}, "key rows [SHIPPED kernels, key-alias launcher]")]
+    for m, exe, leg_env, label in legs:
+        if not Path(exe).exists():
+            continue
+        env = dict(env0, **leg_env)
+        e = {"stream_aliased": label, "per_kernel": {}}
+        groups = ["tcp", "tcc", "fetch", "write"] + (["sq"] if m in ("0", "shipped") else [])
         allv, alld = {}, {}
         for grp in groups:
             try:
@@ -160,7 +170,7 @@ def main():
         except Exception as ex:
             e["power_leg"] = {"error": str(ex)[:200]}
         res["masks"][str(m)] = e
-        print(f"mask {m:2d} ({e['stream_aliased']}): " + json.dumps({**{k: round(v / 1e6, 3) for k, v in tot.items() if k.endswith('_bytes')},
+        print(f"mask {m:>12} ({e['stream_aliased']}): " + json.dumps({**{k: round(v / 1e6, 3) for k, v in tot.items() if k.endswith('_bytes')},
                                                                      **{k: e['power_leg'].get(k) for k in ('keyswitch_per_s', 'board_power_w_mean', 'sclk_mhz_mean', 'mj_per_keyswitch')}}), flush=True)
 
     # per-stream shares: (real pipeline) - (that stream aliased)
@@ -179,11 +189,19 @@ def main():
                 s["sclk_mhz_when_aliased"] = ap_["sclk_mhz_mean"]
             shares[STREAM.get(m, str(m))] = s
         res["stream_shares"] = shares
+    sh, sk = res["masks"].get("shipped", {}), res["masks"].get("shipped_keys", {})
+    if sh.get("pipeline") and sk.get("pipeline"):
+        res["shipped_kernels"] = {
+            "fabric_read_bytes": sh["pipeline"].get("fabric_read_bytes"), "fabric_write_bytes": sh["pipeline"].get("fabric_write_bytes"),
+            "key_stream_fabric_read_bytes": sh["pipeline"].get("fabric_read_bytes", 0.0) - sk["pipeline"].get("fabric_read_bytes", 0.0),
+            "throughput_gain_when_keys_aliased": (sk.get("power_leg", {}).get("keyswitch_per_s", 0.0) / sh["power_leg"]["keyswitch_per_s"] - 1.0)
+            if sh.get("power_leg", {}).get("keyswitch_per_s") else None,
+            "note": "the figures bench.py's roofline block reports (traffic, key_stream_bytes_per_keyswitch): same kernel objects in both legs"}
         res["stream_shares_note"] = ("bytes: what leaves the counters when a stream reads one row (its L2-miss-side share; the CU-side requests stay, they "
                                      "only hit); energy / throughput: what the pipeline gains when that stream costs (almost) nothing -- an upper bound on what "
                                      "any re-layout of that stream can buy")
-    (out / "r04_bytes.json").write_text(json.dumps(res, indent=1))
-    print("wrote", out / "r04_bytes.json")
+    (out / "r05_bytes.json").write_text(json.dumps(res, indent=1))
+    print("wrote", out / "r05_bytes.json")
 
 
 if __name__ == "__main__":

@@ -25,6 +25,23 @@ __global__ void k_read8_strided(const unsigned long long* p, size_t n, unsigned 
         for (int r = 0; r < 4; ++r) acc += p[base + size_t(threadIdx.x) * 4 + r];
     if (acc == 0x1234567) *sink = acc;
 }
+// the key stream's instruction: buffer_load_dwordx2 through a resource descriptor, the thread's byte offset in a VGPR, the ROW offset in an
+// SGPR (RowStream, ntt_core.hpp), 8 B per lane, rows of 128 KiB walked 16 words per thread as mac_keys does
+__global__ __launch_bounds__(1024) void k_read8_buffer_rows(const unsigned long long* p, size_t rows, unsigned long long* sink) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    unsigned long long acc = 0;
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const unsigned long long base = (unsigned long long)(p + row * 16384);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 131072, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(threadIdx.x * 8), r * 8192, 0);
+            acc += x.x ^ x.y;
+        }
+    }
+    if (acc == 0x1234567) *sink = acc;
+}
 __global__ void k_write8(unsigned long long* p, size_t n) {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) p[i] = i;
 }
@@ -35,12 +52,13 @@ __global__ void k_write16(ulonglong2* p, size_t n) {
 int main() {
     const size_t GiB = size_t(1) << 30;
     char* buf; unsigned long long* sink;
-    hipMalloc(&buf, 5 * GiB); hipMalloc(&sink, 8);
-    hipMemset(buf, 1, 5 * GiB);
+    hipMalloc(&buf, 6 * GiB); hipMalloc(&sink, 8);
+    hipMemset(buf, 1, 6 * GiB);
     hipDeviceSynchronize();
     hipLaunchKernelGGL(k_read16, dim3(4096), dim3(256), 0, 0, (const ulonglong2*)(buf + 0 * GiB), GiB / 16, sink);
     hipLaunchKernelGGL(k_read8, dim3(4096), dim3(256), 0, 0, (const unsigned long long*)(buf + 1 * GiB), GiB / 8, sink);
     hipLaunchKernelGGL(k_read8_strided, dim3(4096), dim3(256), 0, 0, (const unsigned long long*)(buf + 2 * GiB), GiB / 8, sink);
+    hipLaunchKernelGGL(k_read8_buffer_rows, dim3(1024), dim3(1024), 0, 0, (const unsigned long long*)(buf + 5 * GiB), GiB / 131072, sink);
     hipLaunchKernelGGL(k_write8, dim3(4096), dim3(256), 0, 0, (unsigned long long*)(buf + 3 * GiB), GiB / 8);
     hipLaunchKernelGGL(k_write16, dim3(4096), dim3(256), 0, 0, (ulonglong2*)(buf + 4 * GiB), GiB / 16);
     hipDeviceSynchronize();

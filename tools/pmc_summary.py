@@ -82,6 +82,47 @@ def derive(vals, dur, batch, L, simds=1024):
     return out
 
 
+NTT_ALG_BYTES = 2 * N * 8          # read + write of the polynomial; tables shared by the batch
+
+
+def derive_ntt(vals, dur, batch=1024, simds=1024, clock_ghz=None):
+    """The standalone _NTT / _INTT launches of the same passes (tools/pmc_workload ... 1: `batch` polynomials per launch, N = 16384, the
+    exact FP64 fast path): per direction the transform kernel + the table-preparation kernel that runs in front of EVERY launch --
+    L2-miss-side bytes and VALU wave-instructions per launch and per transform, duration under the counters, FP64-issue fraction.
+    A 70 us dispatch is too short for its own GRBM_GUI_ACTIVE reading (pmc_summary.derive): `clock_ghz` = the keyswitch passes' clock."""
+    out = {}
+    prep = [k for k in vals if k.startswith("k_ntt_prepare")]
+    for name, pref in (("fwd", "k_ntt_fwd_"), ("inv", "k_ntt_inv_")):
+        ks = [k for k in vals if k.startswith(pref)]
+        if not ks:
+            continue
+        k = max(ks, key=lambda kk: sum(dur.get(kk, [0.0])))
+        v, d = vals[k], sum(dur[k]) / len(dur[k])
+        e = {"kernel": k, "avg_us_under_pmc": d, "batch": batch, "alg_bytes_per_launch": batch * NTT_ALG_BYTES}
+        if prep:
+            pv, pd = vals[prep[0]], sum(dur[prep[0]]) / len(dur[prep[0]])
+            e["prepare_kernel_avg_us_under_pmc"] = pd
+        else:
+            pv, pd = {}, 0.0
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            e["read_bytes_per_launch"] = (v["FETCH_SIZE"] + pv.get("FETCH_SIZE", 0.0)) * 1024 * 2
+            e["write_bytes_per_launch"] = (v["WRITE_SIZE"] + pv.get("WRITE_SIZE", 0.0)) * 1024
+            e["traffic_bytes_per_launch"] = e["read_bytes_per_launch"] + e["write_bytes_per_launch"]
+            e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / e["alg_bytes_per_launch"]
+        if "SQ_INSTS_VALU" in v:
+            e["valu_wave_instructions_per_launch"] = v["SQ_INSTS_VALU"] + pv.get("SQ_INSTS_VALU", 0.0)
+            e["valu_wave_instructions_per_transform"] = v["SQ_INSTS_VALU"] / batch
+            if clock_ghz:
+                e["shader_clock_ghz"] = clock_ghz
+                e["fp64_issue_frac_under_pmc"] = v["SQ_INSTS_VALU"] * 4 / simds / (clock_ghz * 1e3) / d
+        if "SQ_WAVE_CYCLES" in v and "SQ_ACTIVE_INST_ANY" in v:
+            wc = v["SQ_WAVE_CYCLES"]
+            e["wave_time_split"] = {"active": v["SQ_ACTIVE_INST_ANY"] / wc, "issue_stall": v["SQ_WAIT_INST_ANY"] / wc,
+                                    "waitcnt_barrier": v["SQ_WAIT_ANY"] / wc}
+        out[name] = e
+    return out
+
+
 def main():
     root, batch, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     vals, dur = collect(root)
