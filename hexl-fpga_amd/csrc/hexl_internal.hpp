@@ -50,6 +50,7 @@ struct hexl_ctx {
     void* d_stage = nullptr;  size_t d_stage_bytes = 0;
     void* d_shared = nullptr; size_t d_shared_bytes = 0;   // small shared arrays of device-resident callers
     void* h_stage = nullptr;  size_t h_stage_bytes = 0;
+    void* h_lone = nullptr;   size_t h_lone_bytes = 0;    // COHERENT pinned slabs of the zero-copy lone keyswitch (capi.hip keyswitch_host_lone)
     uint32_t lone_epoch = 0;                                // zero-copy lone keyswitches so far (their completion words carry it)
     // host-pointer pipeline: copy streams + events (created lazily), see run_pipeline() in capi.hip
     hipStream_t s_up = nullptr, s_down = nullptr;
@@ -65,7 +66,7 @@ struct hexl_ctx {
 };
 
 int hx_reserve_device(hexl_ctx* ctx, void** p, size_t* cur, size_t need);
-int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need);
+int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need, bool coherent = false);
 
 // per-modulus constants of a keyswitch plan (device copy is an array of K of these)
 struct KsModulus {
