@@ -45,24 +45,126 @@ using namespace hx;
 // centred double tables; the transform kernels then choose per polynomial, falling back to the integer
 // butterflies whenever a precondition fails, so every input still gets the reference's exact answer.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q, u32 n,
-                              double* __restrict__ w, double* __restrict__ wp, u32* __restrict__ violations,
-                              u32* __restrict__ zero_for_later) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // index 0 is never read by either transform; its thread resets the counter a launch 32 launches from now will use
-    if (i == 0) { w[0] = 0.0; *zero_for_later = 0; return; }
+// one table entry i != 0: verify the Shoup pair (false: it is not one), derive the centred double(s)
+__device__ __forceinline__ bool prepare_entry(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q, u32 i,
+                                              double* w, double* wp) {
     const u64 r = roots[i], p = precon[i];
     // 128-bit  D = r*2^64 - p*q  must satisfy 0 <= D < q
     const u64 lo = p * q, hi = mulhi(p, q);
     const u64 d_lo = 0 - lo, d_hi = r - hi - (lo != 0);
     const bool ok = (r < q) && (hi + (lo != 0) <= r) && (d_hi == 0) && (d_lo < q);
-    if (!ok) atomicAdd(violations, 1u);
     const double pd = (double)q;
     const u64 rr = r < q ? r : 0;
     const double c = rr > q / 2 ? (double)rr - pd : (double)rr;
     w[i] = c;          // (the lazy transforms take their quotients from the products: no w/p table, f64_arith.hpp)
     if (pd > hxf::LAZY_MAX_MODULUS) wp[i] = c / pd;                  // strict tier: the semi-strict forward schedule reads it
+    return ok;
+}
+
+// What a launch needs to know about its tables. The counters come from rings of 64 slots (one per launch, round robin: no memset per
+// launch -- the preparation of launch k zeroes the slots launch k + 32 will use, long after their last reader has finished on this stream).
+struct NttPrep {
+    double* w; double* wp;               // derived tables: written by the preparation, read by the transforms (never restrict / const here)
+    u32* viol; u32* viol_later;          // entries that are not Shoup pairs, this launch's slot / the slot zeroed for launch + 32
+    // fused launches (the persistent grid prepares for itself, ntt_tables_ready): EIGHT copies of the tables, one per XCD, at
+    // w + x * 2 n (its w/p table n further), and per XCD a cache line of its own (NTT_RING_STRIDE words) with a ticket and a ready
+    // counter in words 0 and 1 (ready: slices done in the low half, slices with a bad entry in the high half): ring[x * NTT_RING_STRIDE + k]
+    u32* ring; u32* ring_later;
+    u32 n, fused;
+};
+
+constexpr u32 NTT_RING_STRIDE = 32;       // 128 bytes: the XCDs poll and count in different cache lines
+
+__global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q, NttPrep pr) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pr.n) return;
+    // index 0 is never read by either transform; its thread resets the counters a launch 32 launches from now will use
+    if (i == 0) {
+        pr.w[0] = 0.0;
+        *pr.viol_later = 0;
+        for (u32 x = 0; x < 8; ++x)
+            for (u32 k = 0; k < 3; ++k) pr.ring_later[x * NTT_RING_STRIDE + k] = 0;
+        return;
+    }
+    // (one atomic per wave that saw a bad entry, not one per entry: random tables -- the reference benchmark's -- fail in every entry)
+    const bool ok = prepare_entry(roots, precon, q, i, pr.w, pr.wp);
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0 && (threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(pr.viol, 1u);
+}
+
+// Round 5 (HEXL_NTT_FUSED_PREPARE=1; measured no faster, off by default -- see fused_prepare_enabled): the preparation INSIDE the persistent
+// transform launch. k_ntt_prepare in front of every launch costs 2.8-5.6 us of kernel plus a dispatch gap -- 7-9 % of a 77 us launch at
+// batch 1024. Every workgroup requests its first polynomial, then helps to prepare the tables and waits for them, so the preparation hides
+// behind the first input's latency.
+// One copy of the tables PER XCD, prepared by workgroups of that XCD and read by workgroups of that XCD only (the wave's XCC_ID hardware
+// register says which): the L2 is per XCD and is the coherence point of its own compute units, so a slice whose stores have been
+// acknowledged (s_waitcnt vmcnt(0): the vector L1 is write-through) is visible to every reader of that XCD -- no L2 write-back, no L2
+// invalidate. (A single table shared by all XCDs needs agent-scope release / acquire: buffer_wbl2 + buffer_inv sc1 in every wave --
+// measured, it DOUBLES the launch time: 6.4 M against 12.8 M NTT/s at batch 1024.) The vector L1 and the scalar cache (the transforms read
+// the table through the constant address space) cannot hold stale lines of it: both are invalidated at dispatch and the table is first
+// touched behind the wait; the pointers handed to the transforms are laundered behind the wait so that no load of the table can be
+// scheduled in front of it. Work is claimed by TICKET per XCD (n / T slices of one entry per thread; eight times the verification work
+// of one table, still half an entry per thread): every workgroup takes one ticket of its XCD on arrival and the first n / T of them
+// prepare that slice -- a workgroup only ever waits for slices whose ticket a RUNNING workgroup holds, so nothing depends on
+// co-residency; it does depend on every XCD receiving at least n / T workgroups of the grid (workgroups go to the XCDs round robin:
+// 32 each of a 256-workgroup grid; the launcher checks).
+// (Round 4's variant had EVERY workgroup verify the whole table -- 16 entries per thread: slower, tools/experiments/ntt_fused_prepare.patch.)
+// the XCD (XCC) this wave runs on: hwreg(HW_REG_XCC_ID) bits 3:0 on gfx942 / gfx950 (what HIP's __smid() reads there too)
+__device__ __forceinline__ u32 hx_xcc_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return u32(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7u;
+#else
+    return 0u;
+#endif
+}
+
+template <int T>
+__device__ __forceinline__ bool ntt_tables_ready(const NttPrep& pr, const u64* __restrict__ roots, const u64* __restrict__ precon,
+                                                 u64 q, const double*& w, const double*& wp) {
+    double *lw = pr.w, *lwp = pr.wp;
+    if (pr.fused) {
+        const u32 xcc = hx_xcc_id();
+        lw += size_t(xcc) * 2 * pr.n;
+        lwp = lw + pr.n;
+        u32 *ticket = pr.ring + xcc * NTT_RING_STRIDE, *ready = ticket + 1;
+        const u32 slices = pr.n / T;
+        // every workgroup takes ONE ticket of its XCD; the first `slices` of them prepare the slice of that number. (The launcher fuses
+        // only when every XCD is sure to receive at least `slices` workgroups of the grid.)
+        __shared__ u32 claimed;
+        if (threadIdx.x == 0) claimed = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 t = claimed;
+        if (t < slices) {
+            const u32 i = t * T + threadIdx.x;
+            bool ok = true;
+            if (i == 0) {
+                lw[0] = 0.0;                                       // (index 0 is never read by either transform)
+                __hip_atomic_store(pr.viol_later, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (u32 k = 0; k < 3; ++k) __hip_atomic_store(pr.ring_later + xcc * NTT_RING_STRIDE + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                ok = prepare_entry(roots, precon, q, i, lw, lwp);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's entries are in the XCD's L2
+            const bool slice_bad = __syncthreads_or(!ok);           // (the barrier the slice needs anyway: ONE violation count per slice)
+            // ONE atomic says both "slice done" (low half) and "it had an entry that is not a Shoup pair" (high half): two counters would
+            // need an ordering between them
+            if (threadIdx.x == 0) atomicAdd(ready, slice_bad ? 0x10001u : 1u);
+        }
+        __shared__ u32 seen;
+        if (threadIdx.x == 0) {
+            u32 v;
+            while (((v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFFu) < slices) __builtin_amdgcn_s_sleep(8);
+            seen = v;
+        }
+        __syncthreads();
+        const double *cw = lw, *cwp = lwp;
+        asm volatile("" : "+s"(cw), "+s"(cwp) :: "memory");        // every table load depends on these: none moves in front of the wait
+        w = cw; wp = cwp;
+        return (seen >> 16) != 0;
+    }
+    const double *cw = lw, *cwp = lwp;
+    asm volatile("" : "+s"(cw), "+s"(cwp) :: "memory");            // every table load depends on these: none moves in front of the wait
+    w = cw; wp = cwp;
+    return __hip_atomic_load(pr.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;       // counted by k_ntt_prepare, a launch of its own
 }
 
 // Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
@@ -257,15 +359,22 @@ struct RangeVote {
 // tools/experiments/persistent_prefetch.patch measured that 10 % SLOWER.)
 template <int LOGN, int LOGE, int LAZY, bool SEMI = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restrict__ x, const u64* __restrict__ roots,
-                                                                  const u64* __restrict__ precon, u64 q,
-                                                                  const double* __restrict__ w,
-                                                                  const double* __restrict__ wp,
-                                                                  const u32* __restrict__ violations, u32 batch, NttHint hint) {
+                                                                  const u64* __restrict__ precon, u64 q, NttPrep prep,
+                                                                  u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
-    const bool bad_tables = *violations != 0;                     // counted by k_ntt_prepare, which runs in front of every launch
+    // the first polynomial is requested before anything is waited for (fused launches: the table preparation hides behind it)
+    u64 raw[G::E];
+    {
+        const int tid = threadIdx.x;
+        const u64* p0 = x + size_t(blockIdx.x) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
+    }
+    const double *w, *wp;
+    const bool bad_tables = ntt_tables_ready<G::T>(prep, roots, precon, q, w, wp);   // counted by the preparation (k_ntt_prepare, or this launch's leading workgroups)
     if (bad_tables) {
         // Tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones): known at kernel entry,
         // the same for every polynomial and wave-uniform -- the whole batch goes straight through the integer butterflies.
@@ -281,13 +390,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
-    u64 raw[G::E];
-    {
-        const int tid = threadIdx.x;
-        const u64* p0 = x + size_t(blockIdx.x) * G::N;
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
-    }
 #pragma unroll 1
     for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
         int tid = threadIdx.x;
@@ -321,15 +423,22 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restrict__ x, const u64* __restrict__ iroots,
                                                                   const u64* __restrict__ iprecon, u64 q, u64 inv_n,
-                                                                  u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p,
-                                                                  const double* __restrict__ w,
-                                                                  const double* __restrict__ wp, hxf::InvScale sc,
-                                                                  const u32* __restrict__ violations, u32 batch, NttHint hint) {
+                                                                  u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, NttPrep prep,
+                                                                  hxf::InvScale sc, u32 batch, NttHint hint) {
     using G = Geom<LOGN, LOGE>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, false);
     const Mod m{(double)q, 1.0 / (double)q};
-    const bool bad_tables = *violations != 0;
+    u64 raw[G::E];                                                // (requested before the wait for the tables: k_ntt_fwd_p)
+    {
+        const int tid = threadIdx.x;
+        const u64* p0 = x + size_t(blockIdx.x) * G::N;
+        const u32 tB = u32(G::idxB(0, tid));
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
+    }
+    const double *w, *wp;
+    const bool bad_tables = ntt_tables_ready<G::T>(prep, iroots, iprecon, q, w, wp);
     if (bad_tables) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
 #if !HX_NTT_NO_SLOW
@@ -342,14 +451,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
-    u64 raw[G::E];
-    {
-        const int tid = threadIdx.x;
-        const u64* p0 = x + size_t(blockIdx.x) * G::N;
-        const u32 tB = u32(G::idxB(0, tid));
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
-    }
 #pragma unroll 1
     for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
         int tid = threadIdx.x;
@@ -402,25 +503,42 @@ static int ensure_ntt_hint(hexl_ctx* ctx) {                        // NttHint: f
     return 0;
 }
 
-// device scratch for the derived tables: [w | w/p] (n doubles each) + the violation counter
-static int prepare_tables(hexl_ctx* ctx, const u64* roots, const u64* precon, u64 q, u64 n, double** w, double** wp,
-                          u32** viol) {
-    // layout: 64 violation counters (one per launch, round robin: no memset per launch -- each launch's prepare kernel
-    // zeroes the counter 32 launches ahead, long after its last reader has finished on this stream), then w, w/p
-    const size_t bytes = 256 + 2 * n * sizeof(double);
+// device scratch for the derived tables: a ring of 64 violation counters (launches with a k_ntt_prepare of their own), a ring of 64 x 24
+// per-XCD counters (fused launches), then eight copies of [w | w/p] (n doubles each; the separate preparation fills copy 0 only)
+static int reserve_tables(hexl_ctx* ctx, u64 n, NttPrep* pr) {
+    constexpr size_t HEAD = 256 + 64 * 8 * NTT_RING_STRIDE * sizeof(u32) + 256;       // 64 violation counters, 64 x 8 ring lines
+    const size_t bytes = HEAD + 8 * 2 * n * sizeof(double);
     const void* before = ctx->d_ntt_tab;
     int rc = hx_reserve_device(ctx, &ctx->d_ntt_tab, &ctx->d_ntt_tab_bytes, bytes);
     if (rc) return rc;
-    if (ctx->d_ntt_tab != before) HX_CHECK(hipMemsetAsync(ctx->d_ntt_tab, 0, 256, ctx->stream));
+    if (ctx->d_ntt_tab != before) HX_CHECK(hipMemsetAsync(ctx->d_ntt_tab, 0, HEAD, ctx->stream));
     u32* counters = (u32*)ctx->d_ntt_tab;
-    *w = (double*)((char*)ctx->d_ntt_tab + 256);
-    *wp = *w + n;
+    pr->w = (double*)((char*)ctx->d_ntt_tab + HEAD);
+    pr->wp = pr->w + n;
     if (int rch = ensure_ntt_hint(ctx)) return rch;
     const u32 seq = ctx->ntt_seq++;
-    *viol = counters + (seq & 63);
-    hipLaunchKernelGGL(k_ntt_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, roots, precon, q,
-                       (u32)n, *w, *wp, *viol, counters + ((seq + 32) & 63));
+    pr->viol = counters + (seq & 63);
+    pr->viol_later = counters + ((seq + 32) & 63);
+    pr->ring = counters + 64 + 8 * NTT_RING_STRIDE * (seq & 63);
+    pr->ring_later = counters + 64 + 8 * NTT_RING_STRIDE * ((seq + 32) & 63);
+    pr->n = (u32)n;
+    pr->fused = 0;
+    return 0;
+}
+// the preparation as a launch of its own, in front of a transform kernel that does not do it itself
+static int launch_prepare(hexl_ctx* ctx, const u64* roots, const u64* precon, u64 q, const NttPrep& pr) {
+    hipLaunchKernelGGL(k_ntt_prepare, dim3((pr.n + 255) / 256), dim3(256), 0, ctx->stream, roots, precon, q, pr);
     return (int)hipGetLastError();
+}
+// HEXL_NTT_FUSED_PREPARE=1: the persistent kernels prepare the tables themselves (ntt_tables_ready) instead of a k_ntt_prepare launch in
+// front of them. Bit-exact (tests/test_gpu_ntt.py runs the suite both ways), and NOT faster -- measured round 5, three interleaved rounds on
+// one box (profiles/r05_ntt_fused_prepare.txt): forward 12.56-12.76 M against 12.86-12.93 M NTT/s at batch 1024, 13.95-14.18 M against
+// 13.96-14.20 M at batch 4096 (inverse alike). The 2.8 us kernel and its dispatch gap do go away, but every workgroup now sits at a barrier
+// behind its first input and a poll of its XCD's counter before its first butterfly, where the separate launch overlaps the previous
+// launch's tail; the two cost the same. OFF by default: the separate launch stays, as in rounds 2-4.
+static bool fused_prepare_enabled() {
+    static const bool on = [] { const char* e = getenv("HEXL_NTT_FUSED_PREPARE"); return e && atoi(e) == 1; }();
+    return on;
 }
 
 template <int LOGN, int LOGE>
@@ -624,8 +742,7 @@ static int launch_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
 }
 
 template <int LOGN, int LOGE, int LAZY, bool SEMI = false>
-static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q,
-                        const double* w, const double* wp, const u32* viol) {
+static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q, NttPrep pr) {
     using G = Geom<LOGN, LOGE>;
     static PerDeviceOnce once;
     if (int rc = once.run(ctx->device, [] {
@@ -644,18 +761,24 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
                 return 0;
             }))
             return rc;
+        // the persistent grid prepares the tables itself (its first n / T workgroups, ntt_tables_ready) -- decided HERE, where the
+        // persistent branch is taken (round 4's experiment re-derived that condition elsewhere)
+        pr.fused = fused_prepare_enabled() && slots / 8 >= pr.n / G::T ? 1u : 0u;   // every XCD receives slots / 8 workgroups
+        if (!pr.fused)
+            if (int rc = launch_prepare(ctx, roots, precon, q, pr)) return rc;
         hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY, SEMI>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
-                           roots, precon, q, w, wp, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+                           roots, precon, q, pr, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         return (int)hipGetLastError();
     }
+    if (int rc = launch_prepare(ctx, roots, precon, q, pr)) return rc;
     hipLaunchKernelGGL((k_ntt_fwd_x<LOGN, LOGE, LAZY, SEMI>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
-                       roots, precon, q, w, wp, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+                       roots, precon, q, (const double*)pr.w, (const double*)pr.wp, (const u32*)pr.viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
     return (int)hipGetLastError();
 }
 
 template <int LOGN, int LOGE, int LAZY>
 static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const u64* ip, u64 q, u64 a, u64 ap, u64 b,
-                        u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* viol) {
+                        u64 bp, NttPrep pr, hxf::InvScale sc) {
     using G = Geom<LOGN, LOGE>;
     static PerDeviceOnce once;
     if (int rc = once.run(ctx->device, [] {
@@ -672,12 +795,16 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
                 return 0;
             }))
             return rc;
+        pr.fused = fused_prepare_enabled() && slots / 8 >= pr.n / G::T ? 1u : 0u;   // see launch_fwd_x
+        if (!pr.fused)
+            if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
         hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
-                           ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+                           ir, ip, q, a, ap, b, bp, pr, sc, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         return (int)hipGetLastError();
     }
+    if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
     hipLaunchKernelGGL((k_ntt_inv_x<LOGN, LOGE, LAZY>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
-                       ir, ip, q, a, ap, b, bp, w, wp, sc, viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+                       ir, ip, q, a, ap, b, bp, (const double*)pr.w, (const double*)pr.wp, sc, (const u32*)pr.viol, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
     return (int)hipGetLastError();
 }
 
@@ -692,34 +819,33 @@ static bool small_e16(int logn, bool fwd) {
 }
 
 template <int LAZY, bool SEMI = false>
-static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, const double* w,
-                          const double* wp, const u32* v) {
+static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, const NttPrep& pr) {
     switch (logn) {
-        case 10: return launch_fwd_x<10, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
-        case 11: return small_e16(11, true) ? launch_fwd_x<11, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v)
-                                   : launch_fwd_x<11, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
-        case 12: return small_e16(12, true) ? launch_fwd_x<12, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v)
-                                   : launch_fwd_x<12, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
-        case 13: return small_e16(13, true) ? launch_fwd_x<13, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v)
-                                   : launch_fwd_x<13, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
-        case 14: return launch_fwd_x<14, 4, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);
-        case 15: return launch_fwd_x<15, 5, LAZY, SEMI>(c, x, batch, r, p, q, w, wp, v);    // beyond the reference: half-size exchanges
+        case 10: return launch_fwd_x<10, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr);
+        case 11: return small_e16(11, true) ? launch_fwd_x<11, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr)
+                                   : launch_fwd_x<11, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);
+        case 12: return small_e16(12, true) ? launch_fwd_x<12, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr)
+                                   : launch_fwd_x<12, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);
+        case 13: return small_e16(13, true) ? launch_fwd_x<13, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr)
+                                   : launch_fwd_x<13, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);
+        case 14: return launch_fwd_x<14, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr);
+        case 15: return launch_fwd_x<15, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);    // beyond the reference: half-size exchanges
         default: return HEXL_E_BADARG;
     }
 }
 template <int LAZY>
 static int dispatch_inv_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64* r, const u64* p, u64 q, u64 a, u64 ap,
-                          u64 b, u64 bp, const double* w, const double* wp, hxf::InvScale sc, const u32* v) {
+                          u64 b, u64 bp, const NttPrep& pr, hxf::InvScale sc) {
     switch (logn) {
-        case 10: return launch_inv_x<10, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 11: return small_e16(11, false) ? launch_inv_x<11, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v)
-                                   : launch_inv_x<11, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 12: return small_e16(12, false) ? launch_inv_x<12, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v)
-                                   : launch_inv_x<12, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 13: return small_e16(13, false) ? launch_inv_x<13, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v)
-                                   : launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 14: return launch_inv_x<14, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
-        case 15: return launch_inv_x<15, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, w, wp, sc, v);
+        case 10: return launch_inv_x<10, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
+        case 11: return small_e16(11, false) ? launch_inv_x<11, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc)
+                                   : launch_inv_x<11, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
+        case 12: return small_e16(12, false) ? launch_inv_x<12, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc)
+                                   : launch_inv_x<12, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
+        case 13: return small_e16(13, false) ? launch_inv_x<13, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc)
+                                   : launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
+        case 14: return launch_inv_x<14, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
+        case 15: return launch_inv_x<15, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
         default: return HEXL_E_BADARG;
     }
 }
@@ -746,24 +872,25 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
     const int logn = ilog2_exact(n);
     ctx->ntt_clear_viol = nullptr;
     if (fast_path_enabled() && q >= (1ull << 16) && q < hxf::STRICT_NTT_MAX_Q) {
-        double *w, *wp; u32* viol;
+        NttPrep pr;
         // a previous call found these tables not to be Shoup tables: the dedicated integer kernels, which also clear the hint
         // once the prepare kernel (still run for a hinted set) finds the tables genuine
         if (int rch = ensure_ntt_hint(ctx)) return rch;
         const bool hinted = ntt_hinted(ctx, roots, precon, q, n, 0);
-        int rc = prepare_tables(ctx, roots, precon, q, n, &w, &wp, &viol);
+        int rc = reserve_tables(ctx, n, &pr);
+        if (!rc && hinted) rc = launch_prepare(ctx, roots, precon, q, pr);      // (the fast-path launchers below prepare for themselves)
         if (rc) return rc;
-        if (hinted) ctx->ntt_clear_viol = viol;
+        if (hinted) ctx->ntt_clear_viol = pr.viol;
         const int period = hxf::lazy_period_for((double)q);       // fewer range reductions for smaller moduli (N = 16384)
         if (!hinted) {
-            if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, w, wp, viol);
-            if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, w, wp, viol);
-            if (period) return dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+            if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, pr);
+            if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, pr);
+            if (period) return dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, pr);
             // strict tier: the plain strict butterflies; HEXL_NTT_SEMI=1 selects the semi-strict forward schedule (f64_arith.hpp
             // ct_bfly_semi) up to 2^52 (1 + 2^-20): bit-exact, 11 instead of 14 instructions per butterfly, but it reads the w/p table
             // too and measured 11.2-11.8 M against 11.5-12.0 M forward NTT/s at batch 1024 (tools/experiments/README.md)
-            return semi_enabled() && (double)q <= hxf::SEMI_MAX_MODULUS ? dispatch_fwd_x<0, true>(logn, ctx, x, batch, roots, precon, q, w, wp, viol)
-                                                                        : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, w, wp, viol);
+            return semi_enabled() && (double)q <= hxf::SEMI_MAX_MODULUS ? dispatch_fwd_x<0, true>(logn, ctx, x, batch, roots, precon, q, pr)
+                                                                        : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, pr);
         }
     }
     switch (logn) {
@@ -785,19 +912,20 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
     const int logn = ilog2_exact(n);
     ctx->ntt_clear_viol = nullptr;
     if (fast_path_enabled() && q >= (1ull << 16) && q < hxf::STRICT_NTT_MAX_Q && a < q && b < q) {
-        double *w, *wp; u32* viol;
+        NttPrep pr;
         if (int rch = ensure_ntt_hint(ctx)) return rch;
         const bool hinted = ntt_hinted(ctx, ir, ip, q, n, 1);     // see hx_launch_ntt_fwd
-        int rc = prepare_tables(ctx, ir, ip, q, n, &w, &wp, &viol);
+        int rc = reserve_tables(ctx, n, &pr);
+        if (!rc && hinted) rc = launch_prepare(ctx, ir, ip, q, pr);
         if (rc) return rc;
-        if (hinted) ctx->ntt_clear_viol = viol;
+        if (hinted) ctx->ntt_clear_viol = pr.viol;
         const double pd = (double)q;
         auto centre = [&](u64 v) { return v > q / 2 ? (double)v - pd : (double)v; };
         hxf::InvScale sc;
         sc.n = centre(a); sc.n_p = sc.n / pd; sc.nw = centre(b); sc.nw_p = sc.nw / pd;
         if (!hinted)
-            return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<3>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol)
-                                               : dispatch_inv_x<0>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, w, wp, sc, viol);
+            return pd <= hxf::LAZY_MAX_MODULUS ? dispatch_inv_x<3>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, pr, sc)
+                                               : dispatch_inv_x<0>(logn, ctx, x, batch, ir, ip, q, a, ap, b, bp, pr, sc);
     }
     switch (logn) {
         case 10: return launch_inv<10, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp);

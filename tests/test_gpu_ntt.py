@@ -341,3 +341,58 @@ def test_moduli_just_above_2p52_take_the_strict_fp64_path(hx, ctx, dev, orc, whi
     # round trip at full batch
     y = run_inv(hx, ctx, dev, run_fwd(hx, ctx, dev, base, t), t)
     assert np.array_equal(y, base)
+
+
+def test_tables_prepared_inside_the_persistent_kernels():
+    """HEXL_NTT_FUSED_PREPARE=1 (ntt.hip ntt_tables_ready; measured no faster than the separate k_ntt_prepare launch and off by default):
+    one copy of the derived tables per XCD, slices claimed by ticket, readers wait on their XCD's counter. Same bits as the oracle on the
+    persistent path (batch > 256) for Shoup tables, for tables EDITED IN PLACE between two calls (the copies must be re-derived by every
+    launch), for tables that are not Shoup tables (every slice reports it; integer butterflies), and across 70 launches (the counter rings
+    wrap at 64)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np, torch, hexl_fpga_amd as hx, orc
+dev = torch.device("cuda:0"); ctx = hx.Context(0)
+n, batch = 16384, 520
+rng = np.random.default_rng(11)
+for bits in (51, 30):
+    q = orc.primes(1, bits, n)[0]
+    t = orc.HexlTables(n, q)
+    x = rng.integers(0, q, size=(8, n), dtype=np.uint64)
+    d_in = hx.as_i64(np.tile(x, (batch // 8, 1)).reshape(-1)).to(dev)
+    tabs = [hx.as_i64(a).to(dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
+    for rep in range(70):
+        d = d_in.clone()
+        ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)
+        if rep %% 23 == 0:
+            ctx.sync(); got = hx.to_u64(d).reshape(batch, n)
+            assert np.array_equal(got[:8], orc.ntt_fwd(x, t)) and np.array_equal(got[-8:], orc.ntt_fwd(x, t)), ("fwd", bits, rep)
+        ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
+        if rep %% 23 == 0:
+            ctx.sync(); assert np.array_equal(hx.to_u64(d).reshape(batch, n)[-8:], x), ("inv", bits, rep)
+    # the same device arrays now hold ANOTHER root's tables: every launch re-derives its copies
+    q2 = orc.primes(2, bits, n)[1]
+    t2 = orc.HexlTables(n, q2)
+    for dst, src in zip(tabs, (t2.roots, t2.precon, t2.inv_roots, t2.inv_precon)):
+        dst.copy_(hx.as_i64(src).to(dev))
+    x2 = x %% q2
+    d = hx.as_i64(np.tile(x2, (batch // 8, 1)).reshape(-1)).to(dev)
+    ctx.ntt_fwd(d, tabs[0], tabs[1], q2, n); ctx.sync()
+    assert np.array_equal(hx.to_u64(d).reshape(batch, n)[-8:], orc.ntt_fwd(x2, t2)), ("edited tables", bits)
+    # not Shoup tables at all
+    t2.roots[:] = rng.integers(0, q2, size=n, dtype=np.uint64); t2.precon[:] = rng.integers(0, q2, size=n, dtype=np.uint64)
+    tabs[0].copy_(hx.as_i64(t2.roots).to(dev)); tabs[1].copy_(hx.as_i64(t2.precon).to(dev))
+    d = hx.as_i64(np.tile(x2, (batch // 8, 1)).reshape(-1)).to(dev)
+    ctx.ntt_fwd(d, tabs[0], tabs[1], q2, n); ctx.sync()
+    assert np.array_equal(hx.to_u64(d).reshape(batch, n)[-8:], orc.ntt_fwd(x2, t2)), ("random tables", bits)
+print("OK")
+''' % (str(root), str(root / "oracle"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, HEXL_NTT_FUSED_PREPARE="1"))
+    print(out.stdout[-500:], out.stderr[-1500:])
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK")
