@@ -259,7 +259,7 @@ extern "C" int hexl_ks_plan_create(hexl_ctx* c, uint64_t n, uint64_t L, uint64_t
         HX_CHECK(hipMalloc((void**)&p->d_mods_f64, K * sizeof(KsModF64)));
         HX_CHECK(hipMalloc((void**)&p->d_tables_f64, ft.size() * sizeof(double)));
         HX_CHECK(hipMalloc((void**)&p->d_keys_f64, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
-        if (logn >= 10 && logn <= 14) HX_CHECK(hipMalloc((void**)&p->d_keys_x, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
+        if (logn >= 10 && logn <= 15) HX_CHECK(hipMalloc((void**)&p->d_keys_x, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
         if (logn == 14) HX_CHECK(hipMalloc((void**)&p->d_keys_nat, size_t(L) * (L + 1) * 2 * n * sizeof(double)));
         HX_CHECK(hipMemcpy(p->d_mods_f64, fm.data(), K * sizeof(KsModF64), hipMemcpyHostToDevice));
         HX_CHECK(hipMemcpy(p->d_tables_f64, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -321,7 +321,20 @@ extern "C" int hexl_ks_set_keys(hexl_ks_plan* p, const uint64_t* const* h_keys) 
     if (p->d_keys_nat) devn.resize(words);
     std::vector<u32> permf, permx;
     if (p->use_f64) { devf.resize(words); permf = ks_perm(p->logn, p->f64_loge); }
-    if (p->d_keys_x) { devx.resize(words); p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4; permx = ks_perm(p->logn, p->x_loge); }
+    if (p->d_keys_x) {
+        devx.resize(words);
+        p->x_loge = p->logn == 14 ? hx_ks_x_loge() : 4;
+        if (p->logn == 15) {
+            // N = 32768: every transform of the slot-major pipeline is two 16384-point halves (keyswitch_x.hip k_ksh_*); NTT-domain block h
+            // of a key row is kept in the B order of THAT geometry
+            const std::vector<u32> half = ks_perm(14, 4);
+            permx.resize(n);
+            for (u32 h = 0; h < 2; ++h)
+                for (u32 j = 0; j < (1u << 14); ++j) permx[h * (1u << 14) + j] = h * (1u << 14) + half[j];
+        } else {
+            permx = ks_perm(p->logn, p->x_loge);
+        }
+    }
     for (u64 d = 0; d < L; ++d) {
         if (!h_keys[d]) return HEXL_E_BADARG;
         for (u64 slot = 0; slot <= L; ++slot) {

@@ -123,6 +123,9 @@ struct KsArgsX {
     const double* keys;      // [L][L+1][2][n] centred, B order of THIS geometry
     double* c;               // [chunk][L][n]   canonical, natural order
     double* s;               // [chunk][2][n]   canonical, natural order
+    // N = 32768 (k_ksh_* kernels): the two 16384-point sub-inverses of every inverse transform, un-scaled, natural order inside each half
+    double* csub;            // [chunk][L][2][n/2]
+    double* ssub;            // [chunk][2][2][n/2]
     const u64* t_target;     // [chunk][L][n]
     u64* result;             // [chunk][2][L][n]
     u32 L, K, nb;
@@ -247,25 +250,27 @@ constexpr int KX_PF = KX_PF_DEPTH;
 #endif
 // NEXTB: the next input is read at the B-order positions of a natural-order array (the raw t_i words of the d == i term,
 // k_ksx_main<..., DL>) instead of the usual A-order rows.
-template <class G, bool FOLD = false, int NEXTB = 0, int PF = KX_PF>
+// CSW: words between the two key components of a row (0: G::N; the N = 32768 kernels work on HALF rows of rows that are 2 G::N long)
+template <class G, bool FOLD = false, int NEXTB = 0, int PF = KX_PF, int CSW = 0>
 __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
                                          const double* __restrict__ k0, const double* __restrict__ next, int tid,
                                          const Mod m, bool next_at_B = false) {
 #if KX_MAC_PRIO
     __builtin_amdgcn_s_setprio(KX_MAC_PRIO - 1);
 #endif
-    const RowStream<double> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
+    constexpr int CS = CSW ? CSW : G::N;
+    const RowStream<double> keys(k0, 2 * CS * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8;
     const bool nb = NEXTB == 1 || (NEXTB == 2 && next_at_B);        // (2: wave-uniform, chosen per call: sixteen scalar selects)
     const u32 ntoff = nb ? u32(G::idxB(0, tid)) * 8 : toff;
     auto next_row = [&](int r) -> u32 { return nb ? u32(G::idxB(r, 0)) * 8 : u32(G::idxA(r, 0)) * 8; };
     double ka[PF], kb[PF];
 #pragma unroll
-    for (int r = 0; r < PF; ++r) { ka[r] = keys.template at<KX_KEY_AUX>(toff, r * G::T * 8); kb[r] = keys.template at<KX_KEY_AUX>(toff, (G::N + r * G::T) * 8); }
+    for (int r = 0; r < PF; ++r) { ka[r] = keys.template at<KX_KEY_AUX>(toff, r * G::T * 8); kb[r] = keys.template at<KX_KEY_AUX>(toff, (CS + r * G::T) * 8); }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
         const double a = ka[r % PF], b = kb[r % PF];
-        if (r + PF < G::E) { ka[r % PF] = keys.template at<KX_KEY_AUX>(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.template at<KX_KEY_AUX>(toff, (G::N + (r + PF) * G::T) * 8); }
+        if (r + PF < G::E) { ka[r % PF] = keys.template at<KX_KEY_AUX>(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.template at<KX_KEY_AUX>(toff, (CS + (r + PF) * G::T) * 8); }
         const double x = v[r];
         v[r] = nxt.template at<KX_NEXT_AUX>(ntoff, next_row(r));
         if constexpr (FOLD) {
@@ -289,18 +294,19 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
 // LAZYFOLD (lazy kernels with the folded multiply-accumulate): nothing is range-reduced here -- t_i < q_i as it comes
 // (k_ksx_intt has checked these very words), |t_i . key mod p| <= (0.5 + 0.378) p = 0.88p by mul_mod's general bound, which
 // mac_fold accepts as an accumulator (|acc| <= 1.6p).
-template <class G, bool LAZYFOLD = false>
+template <class G, bool LAZYFOLD = false, int CSW = 0>
 __device__ __forceinline__ void mac_keys_first(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
                                                const u64* __restrict__ t, const double* __restrict__ k0,
                                                const double* __restrict__ next, int tid, const Mod m) {
     static_assert(G::KL <= 2, "direct B-order loads");
-    const RowStream<double> keys(k0, 2 * G::N * 8), nxt(next, G::N * 8);
+    constexpr int CS = CSW ? CSW : G::N;
+    const RowStream<double> keys(k0, 2 * CS * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8, tB = u32(G::idxB(0, tid));
     u64 raw[G::E];
 #pragma unroll
     for (int r = 0; r < G::E; ++r) raw[r] = (t + G::idxB(r, 0))[tB];
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) { acc0[r] = keys.at(toff, r * G::T * 8); acc1[r] = keys.at(toff, (G::N + r * G::T) * 8); }
+    for (int r = 0; r < G::E; ++r) { acc0[r] = keys.at(toff, r * G::T * 8); acc1[r] = keys.at(toff, (CS + r * G::T) * 8); }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
         v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
@@ -516,13 +522,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 #ifndef KX_RMW_PREF
 #define KX_RMW_PREF 0
 #endif
-template <class G, class W, int FUSED_K = -1, bool SKIP = false, int PREF = 0>
+// PRED (the N = 32768 kernels): v arrives ready for the sub-transform (already reduced / combined across the halves); `top` = which half
+template <class G, class W, int FUSED_K = -1, bool SKIP = false, int PREF = 0, bool PRED = false>
 __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
                                                double* lds, int tid, const double* tb, const KsModF64& md, hxf::RangeMask& bad,
                                                const u64* a0 = nullptr, const u64* a1 = nullptr, const u64* b0 = nullptr,
-                                               const u64* b1 = nullptr) {
+                                               const u64* b1 = nullptr, u32 top = 0) {
     const Mod m = md.m;
-    if constexpr (!SKIP) {
+    if constexpr (!SKIP && !PRED) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
     }
@@ -536,7 +543,7 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
         };
         W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m, typename W::NoHook(), request);
     } else {
-        W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m);           // |w| <= 2.14p
+        W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m, typename W::NoHook(), typename W::NoHook(), top);   // |w| <= 2.14p
     }
 #if KX_EPI_PRIO
     __builtin_amdgcn_s_setprio(KX_EPI_PRIO - 1);
@@ -864,6 +871,216 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     }
 }
 
+// =====================================================================================================================================
+// N = 32768 on the slot-major pipeline (round 5; beyond the reference's envelope). 64 registers of polynomial + 128 of
+// accumulators do not fit a 1024-thread workgroup, so every 32768-point transform is cut in TWO, the way keyswitch_lat.hip
+// cuts a 16384-point one in four: its outermost stage is a radix-2 step across the two halves of the polynomial, the other fourteen are
+// two independent 16384-point sub-transforms (WgNttF64<14, 4, ..., TOP = 1>: stage numbers, reduction schedule and twiddle indices of
+// the full transform, the half number on top of every group index). A workgroup = one (instance, limb, HALF) with the geometry, the
+// registers and the multiply-accumulate of the N = 16384 kernels:
+//   k_ksh_intt    (b, d, h)   fourteen inverse stages on half h of t_target[d] (NTT-domain block h)               -> csub (raw)
+//   k_ksh_finish              the inverse's last stage (n^-1 folded in) across the two halves, elementwise         -> c / y
+//   k_ksh_special (b, h)      per d: c_d's halves are combined ON LOAD by the forward transform's first stage (the workgroup reads
+//                             both, keeps the half it owns), fourteen forward stages, multiply-accumulate with its half of the key
+//                             rows; then fourteen inverse stages on its half of the accumulators                     -> ssub (raw)
+//   k_ksh_main    (b, i, h)   the same mod-up, the d == i term from its block of t_target[i], the two mod-down rounds on its
+//                             block of result[k][i]
+// The NTT-domain index space splits into contiguous blocks (sub-transform h produces / consumes block h), so t_target, the keys and
+// result need no exchange at all; only the coefficient-domain arrays (c_d, s') are read in full by both halves: + 1 load, a reduction and
+// 7 FP64 operations per coefficient and round. Same arithmetic as the monolithic transforms of the (b, d)-major kernels: bit-identical.
+template <class G, int LAZY, bool SKIP, int SHIFT>
+__device__ __forceinline__ void ksh_combine(double (&v)[G::E], const double* __restrict__ hi_row, int tid, const double* w, const Mod m, u32 h) {
+    // forward global stage 1 of the 2^15-point transform (one twiddle: index 1), this workgroup keeps output half h
+    const double W1 = ((ctw_t)w)[1];
+    double hi[G::E];
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) hi[r] = (hi_row + G::idxA(r, 0))[u32(tid)];
+    constexpr bool red = LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, SHIFT);   // (the transform's own schedule)
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+        double lo = v[r], y = hi[r];
+        if constexpr (!SKIP) { lo = hxf::reduce(lo, m); y = hxf::reduce(y, m); }        // intt1_redu.hpp:36-42 / intt2_redu.hpp:49-51
+        const double t = hxf::mul_mod(y, W1, m);
+        const double o = h ? lo - t : lo + t;
+        v[r] = red ? hxf::reduce(o, m) : o;
+    }
+}
+
+template <int LAZY>
+__global__ __launch_bounds__(1024, 4) void k_ksh_intt(KsArgsX a) {
+    using G = Geom<14, 4>;
+    using W = WgNttF64<14, 4, LAZY, 0, 0, 0, true, HX_FWD_PRIO, false, 1>;
+    constexpr u32 NF = 2 * G::N;
+    extern __shared__ __attribute__((aligned(16))) double ldsx[];
+    const XcdWalk wk = xcd_walk(a.nb * a.nsel * 2);
+    hxf::RangeMask bad = 0;
+#pragma unroll 1
+    for (u32 unit = wk.pos; unit < wk.end; unit += wk.step) {     // unit = (b * nsel + number of d among this launch's limbs) * 2 + h
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const u32 h = unit & 1, item = unit >> 1, ib = item / a.nsel;
+        const u32 d = __builtin_amdgcn_readfirstlane(sel_limb(a, item - ib * a.nsel));
+        const u32 row = ib * a.L + d;
+        const KsModF64 md = a.mods[d];
+        u32 toff = d * 4 * NF;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        const u64* src = a.t_target + size_t(row) * NF + h * G::N;
+        const u64 qd = (u64)md.m.p;
+        const u32 tB = u32(G::idxB(0, tid));
+        double v[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);    // canonical words as they are
+        W::template inverse<false>(v, ldsx, tid, tb + 2 * NF, tb + 3 * NF, md.m, md.sc, typename W::NoHook(), h);
+        double* dst = a.csub + (size_t(row) * 2 + h) * G::N;
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) (dst + G::idxA(r, 0))[u32(tid)] = v[r];
+    }
+    hxf::report_range(bad, a.range_flag);
+}
+
+// the last inverse stage across the halves, n^-1 folded in (inv_stages_f64's fused last stage on register pairs), then what the
+// consumers read: WHICH = 0: c_d canonical (rows b * L + d of this launch's limbs), 1: y_k = s'_k - floor(q_sp / 2), the exact centred
+// remainder (ksx_special_down). Elementwise, HBM-bound, a few microseconds per chunk.
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_ksh_finish(KsArgsX a, u32 rows) {
+    constexpr u32 H = 1u << 14, NF = 2 * H;
+    const u32 row = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows || j >= H) return;
+    const u32 limb = WHICH == 0 ? row % a.L : a.K - 1;
+    const KsModF64 md = a.mods[limb];
+    const double* tb = a.tables + size_t(limb) * 4 * NF;
+    const double* sub = (WHICH == 0 ? a.csub : a.ssub) + size_t(row) * NF;
+    double x[2] = {sub[j], sub[H + j]};
+    inv_stages_f64<2, 0, 1, 14, 15, true, 3, true, 0, true>(x, 0u, tb + 2 * NF, tb + 3 * NF, md.m, md.sc);
+    double* dst = (WHICH == 0 ? a.c : a.s) + size_t(row) * NF;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double c = hxf::lift(x[k], md.m);
+        dst[k * H + j] = WHICH == 0 ? c : (c > md.half ? c - md.m.p : c);
+    }
+}
+
+template <int LAZY, bool SKIP>
+__global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
+    using G = Geom<14, 4>;
+    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, false, 1>;
+    constexpr u32 NF = 2 * G::N;
+    constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
+    extern __shared__ __attribute__((aligned(16))) double ldsx[];
+    const u32 L = a.L, isp = a.K - 1;
+    const KsModF64 msp = a.mods[isp];
+    const XcdWalk wk = xcd_walk(a.nb * 2);
+#pragma unroll 1
+    for (u32 unit = wk.pos; unit < wk.end; unit += wk.step) {
+        const u32 h = unit & 1, b = unit >> 1;
+        double acc0[G::E], acc1[G::E], v[G::E];
+        {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const double* c0 = a.c + size_t(b) * L * NF;
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = (c0 + G::idxA(r, 0))[u32(tid)]; }
+        }
+#pragma unroll 1
+        for (u32 it = 0; it < L; ++it) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            u32 tsp = isp * 4 * NF;
+            asm volatile("" : "+s"(tsp));
+            const double* ts = a.tables + tsp;
+            ksh_combine<G, LAZY, SKIP, (SKIP ? 1 : 0)>(v, a.c + (size_t(b) * L + it) * NF + G::N, tid, ts, msp.m, h);
+            const double* k0 = key_row<G>(a, it, L) + h * G::N;
+            const u32 nd = it + 1 < L ? it + 1 : it;
+            W::template forward<false, false>(v, ldsx, tid, ts, ts + NF, msp.m, typename W::NoHook(), typename W::NoHook(), h);
+            mac_keys<G, FOLD, 0, KX_PF, int(NF)>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * NF, tid, msp.m);
+        }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            u32 tsp = isp * 4 * NF;
+            asm volatile("" : "+s"(tsp));
+            const double* ts = a.tables + tsp;
+            double (&acc)[G::E] = k == 0 ? acc0 : acc1;
+            W::template inverse<false>(acc, ldsx, tid, ts + 2 * NF, ts + 3 * NF, msp.m, msp.sc, typename W::NoHook(), h);
+            double* dst = a.ssub + ((size_t(b) * 2 + k) * 2 + h) * G::N;
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) (dst + G::idxA(r, 0))[u32(tid)] = acc[r];
+        }
+    }
+}
+
+template <int LAZY, bool SKIP>
+__global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
+    using G = Geom<14, 4>;
+    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, 0, false, HX_FWD_PRIO, false, 1>;                 // mod-down transforms: centred input
+    using WU = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, false, 1>;     // mod-up transforms
+    constexpr u32 NF = 2 * G::N;
+    constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
+    constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
+    extern __shared__ __attribute__((aligned(16))) double ldsx[];
+    const u32 L = a.L;
+    const u32 unit = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));   // (b * nsel + limb number) * 2 + h, XCD-contiguous
+    const u32 h = unit & 1, item = unit >> 1;
+    const u32 b = item / a.nsel, i = sel_limb(a, item - b * a.nsel);
+    const KsModF64 md = load_mod_const(a.mods + i);
+    const Mod m = md.m;
+    auto round_src = [&](u32 it) { return it < L ? a.c + (size_t(b) * L + it) * NF : a.s + (size_t(b) * 2 + (it - L)) * NF; };
+    const u32 first = i == 0 ? 1u : 0u;
+    double acc0[G::E], acc1[G::E], v[G::E];
+    {
+        // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i -- this workgroup's block of it
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        mac_keys_first<G, LAZYFOLD, int(NF)>(acc0, acc1, v, a.t_target + (size_t(b) * L + i) * NF + h * G::N, key_row<G>(a, i, i) + h * G::N,
+                                             round_src(first), tid, m);
+    }
+#pragma unroll 1
+    for (u32 it = first; it < L;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 toff = i * 4 * NF;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        ksh_combine<G, LAZY, SKIP, (SKIP ? 1 : 0)>(v, round_src(it) + G::N, tid, tb, m, h);
+        u32 nit = it + 1;
+        if (nit == i) ++nit;
+        const double* k0 = key_row<G>(a, it, i) + h * G::N;
+        WU::template forward<false, false>(v, ldsx, tid, tb, tb + NF, m, typename WU::NoHook(), typename WU::NoHook(), h);
+        mac_keys<G, FOLD, 0, KX_PF, int(NF)>(acc0, acc1, v, k0, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
+        it = nit;
+    }
+    if constexpr (FOLD && LAZY == 0) {
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
+    }
+    hxf::RangeMask bad = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 toff = i * 4 * NF;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        // y_k (SKIP: |y| <= 0.625 q_i as it is, standard schedule) -> first stage across its halves -> this workgroup's half
+        ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L + k) + G::N, tid, tb, m, h);
+        u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * NF + h * G::N;
+        if (k == 0) ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc0, res, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
+        else        ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc1, res, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
+        if (k == 0) {
+            const double* nxt = round_src(L + 1);
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
+        }
+    }
+    hxf::report_range(bad, a.range_flag);
+}
+
 // ---------------------------------------------------------------------------------------------
 // HEXL_KSX_DIAG=0: k_ksx_main starts with the d == i term as in rounds 2-3 (tests, comparisons)
 static bool diag_late_enabled() {
@@ -979,6 +1196,66 @@ static int run_chunk_x(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* e
     return (int)hipGetLastError();
 }
 
+// one chunk at N = 32768 (k_ksh_* kernels: every transform as two 16384-point halves). Tiers: strict / period 3 only (a shorter period
+// is always valid); limbs of different tiers get a launch per tier like run_chunk_x.
+template <int LAZY, bool SKIP>
+static int launch_stage_h(hexl_ks_plan* p, const KsArgsX& a, int stage) {
+    using G = Geom<14, 4>;
+    static PerDeviceOnce once;
+    if (int rc0 = once.run(p->ctx->device, [] {
+            int rc = set_lds_x(k_ksh_intt<LAZY>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksh_special<LAZY, SKIP>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksh_main<LAZY, SKIP>, G::LDS_USED);
+            return rc;
+        }))
+        return rc0;
+    hipStream_t st = p->cur;
+    auto grid_for = [&](u32 items) {
+        const u32 per_xcd = (items + 7) / 8, slots = ((u32)p->ctx->num_cu + 7) / 8;
+        return dim3(8 * (per_xcd > slots ? slots : per_xcd));
+    };
+    if (stage == 1) hipLaunchKernelGGL((k_ksh_intt<LAZY>), grid_for(a.nb * a.nsel * 2), dim3(G::T), G::LDS_USED, st, a);
+    if (stage == 2) hipLaunchKernelGGL((k_ksh_special<LAZY, SKIP>), grid_for(a.nb * 2), dim3(G::T), G::LDS_USED, st, a);
+    if (stage == 4) hipLaunchKernelGGL((k_ksh_main<LAZY, SKIP>), dim3(a.nb * a.nsel * 2), dim3(G::T), G::LDS_USED, st, a);
+    return 0;
+}
+static int launch_stage_h_tier(hexl_ks_plan* p, const KsArgsX& a, int stage, int tier, bool skip) {
+    if (!tier) return launch_stage_h<0, false>(p, a, stage);
+    return skip ? launch_stage_h<3, true>(p, a, stage) : launch_stage_h<3, false>(p, a, stage);
+}
+static int run_chunk_h(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* ev) {
+    hipStream_t st = p->cur;
+    const u32 L = a.L;
+    auto tier_of = [&](u32 i) { return p->mixed ? (p->tier[i] ? 3 : 0) : (p->f64_lazy ? 3 : 0); };
+    auto per_group = [&](int stage) -> int {
+        bool done[16] = {};
+        for (u32 i0 = 0; i0 < L; ++i0) {
+            if (done[i0]) continue;
+            a.nsel = 0; a.selmap = 0;
+            for (u32 i = i0; i < L; ++i)
+                if (!done[i] && tier_of(i) == tier_of(i0)) { done[i] = true; a.selmap |= (unsigned long long)i << (4 * a.nsel++); }
+            if (int rc = launch_stage_h_tier(p, a, stage, tier_of(i0), p->x_skip)) return rc;
+        }
+        return 0;
+    };
+    if (ev) HX_CHECK(hipEventRecord(ev[0], st));
+    if (stage_mask & 1) {
+        if (int rc = per_group(1)) return rc;
+        hipLaunchKernelGGL((k_ksh_finish<0>), dim3((1u << 14) / 256, a.nb * L), dim3(256), 0, st, a, a.nb * L);
+    }
+    if (ev) HX_CHECK(hipEventRecord(ev[1], st));
+    if (stage_mask & 2) {
+        a.nsel = L; a.selmap = 0xFEDCBA9876543210ull;
+        if (int rc = launch_stage_h_tier(p, a, 2, tier_of(a.K - 1), p->x_skip)) return rc;
+        hipLaunchKernelGGL((k_ksh_finish<1>), dim3((1u << 14) / 256, a.nb * 2), dim3(256), 0, st, a, a.nb * 2);
+    }
+    if (ev) HX_CHECK(hipEventRecord(ev[2], st));
+    if (stage_mask & 4)
+        if (int rc = per_group(4)) return rc;
+    if (ev) HX_CHECK(hipEventRecord(ev[3], st));
+    return (int)hipGetLastError();
+}
+
 size_t hx_ks_x_scratch_words(size_t L) { return L + 2; }   // per instance, in units of n (fits the (b, d)-major scratch)
 
 // Large chunks of N = 16384 instances: one workgroup per (instance, limb) must fill the chip at least twice, like the
@@ -989,7 +1266,8 @@ u32 hx_ks_x_loge() {                                              // HEXL_KSX_LO
 }
 bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
     static const int pipe = [] { const char* e = getenv("HEXL_KS_PIPE"); return e ? atoi(e) : 2; }();
-    if (!p->d_keys_x || p->logn < 10 || p->logn > 14) return false;
+    if (!p->d_keys_x || p->logn < 10 || p->logn > 15) return false;
+    if (p->logn == 15 && p->x_loge != 4) return false;              // (N = 32768: the 16 x 1024 half-transform kernels only)
     // one workgroup per (instance, limb) must nearly fill the chip twice (a CU holds 16384 / N of them): measured at N = 16384,
     // L = 7 (tools/batch_sweep.py) the slot-major pipeline wins from 64 instances up (141 k against 132 k keyswitch/s), the
     // (b, d)-major one below 48
@@ -1024,6 +1302,8 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
     a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_x;
     a.c = (double*)p->cur_scratch;
     a.s = a.c + p->cap * L * n;
+    a.csub = a.s + p->cap * 2 * n;                                  // (N = 32768 only; inside the (b, d)-major scratch, which is larger)
+    a.ssub = a.csub + p->cap * L * n;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = a.mul_b = nullptr;
@@ -1037,6 +1317,7 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
         case 12: return run_chunk_x<12, 4>(p, a, stage_mask, ev);
         case 13: return run_chunk_x<13, 4>(p, a, stage_mask, ev);
         case 14: break;
+        case 15: return run_chunk_h(p, a, stage_mask, ev);           // two 16384-point halves per transform (k_ksh_*)
         default: return HEXL_E_BADARG;
     }
     // (the kernels' LAZY template argument = forward reduction period of the transforms, f64_arith.hpp: launch_stage_tier)

@@ -279,11 +279,23 @@ __device__ __forceinline__ void hx_inv_prio() {
 #endif
 // FSHIFT: phase of the forward reduction schedule (1: un-centred inputs, f64_arith.hpp); NOWP: inverse transforms without
 // the w/p table
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, bool SEMI = false>
+// TOP > 0 (round 5: the slot-major keyswitch at N = 32768): this workgroup transforms ONE of the 2^TOP blocks of a 2^(LOGN + TOP)-point
+// transform -- the inner LOGN stages, i.e. global forward stages TOP + 1 ... TOP + LOGN (global inverse stages 1 ... LOGN), with the stage
+// numbers (reduction schedule), table size and twiddle group indices of the FULL transform; `top` (wave-uniform) = which block. The
+// outer TOP stages are the caller's: a radix-2 step across the blocks on load / in a finishing pass (keyswitch_x.hip HALF kernels), the
+// same cut keyswitch_lat.hip makes in four (WgSubNtt).
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, bool SEMI = false, int TOP = 0>
 struct WgNttF64 {
     static_assert(!SEMI || (LAZY == 0 && PRE == 0 && TF == 0), "semi-strict forward transforms: strict kernels, plain twiddle loads");
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
+    static constexpr int FLOGN = LOGN + TOP;                      // log2 of the full transform
+    // group index of the full transform for a local one at the pass whose first LOCAL stage is S0L (forward) ...
+    template <int S0L>
+    __device__ static __forceinline__ u32 gfwd(u32 top, u32 Gl) { if constexpr (TOP > 0) return (top << (S0L - 1)) | Gl; else return Gl; }
+    // ... and for an inverse call that covers local stages LO + 1 ... LO + K
+    template <int LO, int K>
+    __device__ static __forceinline__ u32 ginv(u32 top, u32 Gl) { if constexpr (TOP > 0) return (top << (LOGN - LO - K)) | Gl; else return Gl; }
 
     // forward: A layout in, B layout out, all values centred. FRESH as in ntt_core.hpp (single-transform kernels).
     // FINAL = false (LAZY only): the range reduction after the last stage is left to the consumer, outputs are
@@ -297,25 +309,26 @@ struct WgNttF64 {
     template <int PASS, bool FRESH = false, bool FINAL = true, class Hook = NoHook, class Hook2 = NoHook>
     __device__ static __forceinline__ void fwd_pass(double (&v)[E], double* lds, int tid, const double* w,
                                                     const double* wp, const Mod m, Hook after_cross = Hook(),
-                                                    Hook2 before_last = Hook2()) {
+                                                    Hook2 before_last = Hook2(), u32 top = 0) {
         hx_fwd_prio<PASS, FPRIO>();
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
-            const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, FSHIFT>(v, Gp, w, m);
-            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT, 0, SEMI>(v, Gp, w, wp, m);
+            const u32 Gl = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
+            const u32 Gp = gfwd<PASS * LOGE + 1>(top, Gl);
+            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, FSHIFT>(v, Gp, w, m);
+            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT, 0, SEMI>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
                 constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;
                 constexpr int NPRE = (PRE % 10) < G::NG ? (PRE % 10) : G::NG;
                 double tl[G::NG][NT];
                 auto request = [&](int g) {
-                    const u32 Gb = u32(G::grpB(g, tid));
+                    const u32 Gb = gfwd<S0L>(top, u32(G::grpB(g, tid)));
 #pragma unroll
                     for (int u = 0; u < G::KL; ++u)
 #pragma unroll
-                        for (int j = 0; j < (1 << u); ++j) tl[g][(1 << u) - 1 + j] = w[(1u << (S0L - 1 + u)) + (Gb << u) + j];
+                        for (int j = 0; j < (1 << u); ++j) tl[g][(1 << u) - 1 + j] = w[(1u << (S0L + TOP - 1 + u)) + (Gb << u) + j];
                 };
 #pragma unroll
                 for (int g = 0; g < NPRE; ++g) request(g);
@@ -329,37 +342,37 @@ struct WgNttF64 {
             }
             redeal_pass<G, LO, LOGE, true, LEAD, (PASS + 1 == G::P - 1)>(v, lds, tid);
             if constexpr (PASS == 0) after_cross();
-            fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m, NoHook(), before_last);
+            fwd_pass<PASS + 1, FRESH, FINAL>(v, lds, tid, w, wp, m, NoHook(), before_last, top);
         } else {
             before_last();
-            fwd_last<0, FINAL>(v, tid, w, wp, m);
+            fwd_last<0, FINAL>(v, tid, w, wp, m, top);
         }
     }
     template <int GRP, bool FINAL = true>
     __device__ static __forceinline__ void fwd_last(double (&v)[E], int tid, const double* w, const double* wp,
-                                                    const Mod m) {
+                                                    const Mod m, u32 top = 0) {
         if constexpr (GRP < G::NG) {
-            const u32 Gbits = u32(G::grpB(GRP, tid));
+            const u32 Gbits = gfwd<(G::P - 1) * LOGE + 1>(top, u32(G::grpB(GRP, tid)));
             // LOGN = 0 tells the stage loop that no stage is the last one
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, false, TF, FSHIFT,
-                           (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? LOGN : 0, SEMI>(v, Gbits, w, wp, m);
-            fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, false, TF, FSHIFT,
+                           (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? FLOGN : 0, SEMI>(v, Gbits, w, wp, m);
+            fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m, top);
         }
     }
     template <int GRP, bool FINAL = true>
     __device__ static __forceinline__ void fwd_last_tw(double (&v)[E], const double (&tl)[G::NG][(1 << G::KL) - 1], const Mod m) {
         if constexpr (GRP < G::NG) {
-            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1, FINAL ? LOGN : 0, LAZY, FSHIFT,
-                              (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? LOGN : 0>(v, tl[GRP], m);
+            fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, FSHIFT,
+                              (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? FLOGN : 0>(v, tl[GRP], m);
             fwd_last_tw<GRP + 1, FINAL>(v, tl, m);
         }
     }
     template <bool FRESH = false, bool FINAL = true, class Hook = NoHook, class Hook2 = NoHook>
     __device__ static __forceinline__ void forward(double (&v)[E], double* lds, int tid, const double* w,
                                                    const double* wp, const Mod m, Hook after_cross = Hook(),
-                                                   Hook2 before_last = Hook2()) {
+                                                   Hook2 before_last = Hook2(), u32 top = 0) {
         static_assert(G::P > 1, "single-pass geometries are not used");
-        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m, after_cross, before_last);
+        fwd_pass<0, FRESH, FINAL>(v, lds, tid, w, wp, m, after_cross, before_last, top);
     }
     // every pass except the last (partial) one, ending with the re-deal into B layout; fwd_last<0> finishes.
     // Lets a persistent kernel slot the next polynomial's loads between the two.
@@ -386,12 +399,12 @@ struct WgNttF64 {
     // inverse: B layout in, A layout out, centred, scaled by n^-1
     template <int GRP, bool IPRE = false>
     __device__ static __forceinline__ void inv_first(double (&v)[E], int tid, const double* iw, const double* iwp,
-                                                     const Mod m, const InvScale sc) {
+                                                     const Mod m, const InvScale sc, u32 top = 0) {
         if constexpr (GRP < G::NG) {
-            const u32 Gbits = u32(G::grpB(GRP, tid));
-            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, NOWP>(v, Gbits, iw, iwp, m, sc);
-            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, LOGN, (G::P == 1), LAZY, false, TF, NOWP>(v, Gbits, iw, iwp, m, sc);
-            inv_first<GRP + 1, IPRE>(v, tid, iw, iwp, m, sc);
+            const u32 Gbits = ginv<0, G::KL>(top, u32(G::grpB(GRP, tid)));
+            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, NOWP>(v, Gbits, iw, iwp, m, sc);
+            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, false, TF, NOWP>(v, Gbits, iw, iwp, m, sc);
+            inv_first<GRP + 1, IPRE>(v, tid, iw, iwp, m, sc, top);
         }
     }
     // `before_uniform` runs once, right after the re-deal that precedes the first pass whose twiddles are wave-uniform
@@ -402,26 +415,28 @@ struct WgNttF64 {
     template <int PASS, bool FRESH = false, class Hook = NoHook, bool IPRE = false>
     __device__ static __forceinline__ void inv_pass(double (&v)[E], double* lds, int tid, const double* iw,
                                                     const double* iwp, const Mod m, const InvScale sc,
-                                                    Hook before_uniform = Hook()) {
+                                                    Hook before_uniform = Hook(), u32 top = 0) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
             constexpr bool LEAD = !(FRESH && PASS == 0);
             hx_inv_prio<PASS + 1>();
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
             if constexpr (inv_pass_uniform<PASS> && (PASS == 0 || !inv_pass_uniform<(PASS > 0 ? PASS - 1 : 0)>)) before_uniform();
-            const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, LOGN, false, LAZY, NOWP>(v, Gp, iw, iwp, m, sc);
-            else inv_stages_f64<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2), LAZY, (PASS == G::P - 2 || LO >= 6), TF, NOWP>(v, Gp, iw, iwp, m, sc);
-            inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform);
+            const u32 Gl = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
+            const u32 Gp = ginv<LO, LOGE>(top, Gl);
+            // (TOP > 0: the transform's last stage -- the one with n^-1 folded in -- is not among these)
+            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, FLOGN, false, LAZY, NOWP>(v, Gp, iw, iwp, m, sc);
+            else inv_stages_f64<E, 0, LOGE, LO, FLOGN, (PASS == G::P - 2 && TOP == 0), LAZY, (PASS == G::P - 2 || LO >= 6), TF, NOWP>(v, Gp, iw, iwp, m, sc);
+            inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform, top);
         }
     }
     template <bool FRESH = false, class Hook = NoHook, bool IPRE = false>
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
                                                    const double* iwp, const Mod m, const InvScale sc,
-                                                   Hook before_uniform = Hook()) {
+                                                   Hook before_uniform = Hook(), u32 top = 0) {
         hx_inv_prio<0>();
-        inv_first<0, IPRE>(v, tid, iw, iwp, m, sc);
-        inv_pass<0, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform);
+        inv_first<0, IPRE>(v, tid, iw, iwp, m, sc, top);
+        inv_pass<0, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform, top);
     }
 };
 
