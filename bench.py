@@ -732,7 +732,7 @@ def main():
                 cs = KsCase(orc_mod, n, Lx, Kx, seed=99, moduli=moduli)
                 pl = hx.KeySwitchPlan(ctx, n, Lx, Kx, Kx, 2, cs.moduli, cs.modswitch)
                 pl.set_keys(cs.keys)
-                nbx = min(mine, 2048) * (N // n)
+                nbx = max(1, min(mine, 2048) * N // n)
                 tx, rx = device_inputs(hx, orc_mod, cs, nbx, dev)
                 pl.keyswitch(rx, tx, nbx)
                 torch.cuda.synchronize()
@@ -787,6 +787,8 @@ def main():
             # the smaller ring dimensions the reference's KeySwitch accepts (host/src/keyswitch.cpp:23-25), decomp 3 / 4 key moduli
             for nx in (8192, 4096, 1024):
                 extra["keyswitch_%d_3_4_4_2" % nx] = other_shape(3, 4, None, nx)
+            # ... and the next ring dimension up (beyond the reference's envelope): every transform as two 16384-point halves
+            extra["keyswitch_32768_3_4_4_2"] = other_shape(3, 4, None, 32768)
             # the headline shape with the LARGEST 52-bit primes = 1 mod 2N (what SEAL's CoeffModulus::Create(n, {52, ...}) picks; `value`
             # uses the smallest ones): above the lazy bound 2^51 (1 + 2^-7), i.e. the STRICT FP64 kernels, 14 instead of 8-11
             # instructions per butterfly -- the slower reading of "52-bit primes", reported beside the faster one

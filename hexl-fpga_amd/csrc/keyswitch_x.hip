@@ -888,21 +888,30 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
 // The NTT-domain index space splits into contiguous blocks (sub-transform h produces / consumes block h), so t_target, the keys and
 // result need no exchange at all; only the coefficient-domain arrays (c_d, s') are read in full by both halves: + 1 load, a reduction and
 // 7 FP64 operations per coefficient and round. Same arithmetic as the monolithic transforms of the (b, d)-major kernels: bit-identical.
+#ifndef KSH_HB
+#define KSH_HB 8      // words of the other half requested at a time in ksh_combine
+#endif
 template <class G, int LAZY, bool SKIP, int SHIFT>
 __device__ __forceinline__ void ksh_combine(double (&v)[G::E], const double* __restrict__ hi_row, int tid, const double* w, const Mod m, u32 h) {
     // forward global stage 1 of the 2^15-point transform (one twiddle: index 1), this workgroup keeps output half h
     const double W1 = ((ctw_t)w)[1];
-    double hi[G::E];
-#pragma unroll
-    for (int r = 0; r < G::E; ++r) hi[r] = (hi_row + G::idxA(r, 0))[u32(tid)];
     constexpr bool red = LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, SHIFT);   // (the transform's own schedule)
+    // the other half's words, HB at a time: all sixteen in flight at once need 32 registers the accumulators do not leave
+    constexpr int HB = KSH_HB;
 #pragma unroll
-    for (int r = 0; r < G::E; ++r) {
-        double lo = v[r], y = hi[r];
-        if constexpr (!SKIP) { lo = hxf::reduce(lo, m); y = hxf::reduce(y, m); }        // intt1_redu.hpp:36-42 / intt2_redu.hpp:49-51
-        const double t = hxf::mul_mod(y, W1, m);
-        const double o = h ? lo - t : lo + t;
-        v[r] = red ? hxf::reduce(o, m) : o;
+    for (int r0 = 0; r0 < G::E; r0 += HB) {
+        double hi[HB];
+#pragma unroll
+        for (int r = 0; r < HB; ++r) hi[r] = (hi_row + G::idxA(r0 + r, 0))[u32(tid)];
+#pragma unroll
+        for (int r = 0; r < HB; ++r) {
+            double lo = v[r0 + r], y = hi[r];
+            if constexpr (!SKIP) { lo = hxf::reduce(lo, m); y = hxf::reduce(y, m); }    // intt1_redu.hpp:36-42 / intt2_redu.hpp:49-51
+            const double t = hxf::mul_mod(y, W1, m);
+            const double o = h ? lo - t : lo + t;
+            v[r0 + r] = red ? hxf::reduce(o, m) : o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1060,23 +1069,28 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
     }
     hxf::RangeMask bad = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    {   // k = 0: y_0 (SKIP: |y| <= 0.625 q_i as it is, standard schedule) -> first stage across its halves -> this workgroup's half
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         u32 toff = i * 4 * NF;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        // y_k (SKIP: |y| <= 0.625 q_i as it is, standard schedule) -> first stage across its halves -> this workgroup's half
-        ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L + k) + G::N, tid, tb, m, h);
-        u64* res = a.result + ((size_t(b) * 2 + k) * L + i) * NF + h * G::N;
-        if (k == 0) ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc0, res, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
-        else        ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc1, res, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
-        if (k == 0) {
-            const double* nxt = round_src(L + 1);
+        ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L) + G::N, tid, tb, m, h);
+        ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc0, a.result + ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, ldsx, tid, tb, md, bad,
+                                                nullptr, nullptr, nullptr, nullptr, h);
+        const double* nxt = round_src(L + 1);
 #pragma unroll
-            for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
-        }
+        for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
+    }
+    {   // k = 1
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u32 toff = i * 4 * NF;
+        asm volatile("" : "+s"(toff));
+        const double* tb = a.tables + toff;
+        ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L + 1) + G::N, tid, tb, m, h);
+        ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc1, a.result + ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N, ldsx, tid, tb, md, bad,
+                                                nullptr, nullptr, nullptr, nullptr, h);
     }
     hxf::report_range(bad, a.range_flag);
 }

@@ -472,10 +472,20 @@ MIXED_TIERS_K4 = {
 
 
 @pytest.mark.parametrize("tier", list(TIERS))
-@pytest.mark.parametrize("n,L,K,nb", [(16384, 6, 7, 70), (16384, 3, 4, 300), (2048, 3, 4, 40)])
+@pytest.mark.parametrize("n,L,K,nb", [(16384, 6, 7, 70), (16384, 3, 4, 300), (2048, 3, 4, 40), (32768, 3, 4, 5)])
 def test_slot_major_kernels_in_every_tier(tier, n, L, K, nb):
     env, moduli = TIERS[tier]
     _alternative(dict(env, HEXL_KS_PIPE="3"), n, L, K, nb, moduli)
+
+
+@pytest.mark.parametrize("L,K,nb,env", [(3, 4, 80, {}), (6, 7, 40, {}), (1, 2, 230, {}), (15, 16, 3, {"HEXL_KS_PIPE": "3"}),
+                                         (2, 7, 5, {"HEXL_KS_PIPE": "3"}), (3, 4, 80, {"HEXL_KS_PIPE": "1"})])
+def test_n32768_on_the_slot_major_pipeline(L, K, nb, env):
+    """Round 5: at N = 32768 every transform of the slot-major pipeline is TWO 16384-point halves (keyswitch_x.hip k_ksh_*:
+    the outermost stage is a radix-2 step across the halves, done on load by the consumer / by the finishing pass of an inverse; one
+    workgroup per (instance, limb, half)). Batches that fill the chip take it by default (nb x L >= 224), HEXL_KS_PIPE=3 forces it,
+    HEXL_KS_PIPE=1 keeps the (b, d)-major kernels: same bits as the oracle on all of them, chunk boundaries included (128 per chunk)."""
+    _alternative(env, 32768, L, K, nb)
 
 
 @pytest.mark.parametrize("tier", list(TIERS))
