@@ -6,7 +6,7 @@ two primitives of that image back to back)."""
 import numpy as np
 import pytest
 
-from ks_util import KsCase, primes_below
+from ks_util import KsCase, primes_below, seal_chain, tier_ladder
 
 pytestmark = pytest.mark.gpu
 
@@ -27,9 +27,15 @@ def composed(orc, case, a, b):
 
 @pytest.mark.parametrize("n,L,K,nb,strict", [(16384, 6, 7, 2, False), (16384, 7, 8, 96, False), (16384, 3, 4, 5, True),
                                              (8192, 3, 4, 70, False), (1024, 2, 3, 300, False), (8192, 2, 3, 3, True),
-                                             (2048, 2, 3, 150, False), (4096, 3, 4, 120, False), (4096, 2, 3, 4, True)])
+                                             (2048, 2, 3, 150, False), (4096, 3, 4, 120, False), (4096, 2, 3, 4, True),
+                                             # round 5: limbs of different tiers (one launch per tier group, keyswitch_x.hip run_chunk_x)
+                                             (16384, 6, 7, 40, "seal"), (16384, 3, 4, 5, "ladder"), (4096, 3, 4, 60, "seal")])
 def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, n, L, K, nb, strict):
-    moduli = primes_below(orc, K, 1 << 52, n) if strict else None      # just below 2^52: the strict FP64 kernels
+    moduli = primes_below(orc, K, 1 << 52, n) if strict is True else None      # just below 2^52: the strict FP64 kernels
+    if strict == "seal":
+        moduli = seal_chain(orc, K, n)
+    elif strict == "ladder":
+        moduli = tier_ladder(orc, K, n)
     case = KsCase(orc, n, L, K, seed=40 + L, moduli=moduli)
     plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch)
     plan.set_keys(case.keys)
