@@ -242,6 +242,10 @@ constexpr int KX_PF = KX_PF_DEPTH;
                     // twice the per-lane twiddle loads and no early requests cost more than the instructions save (19 spilled VGPRs)
 #endif
 #define KX_SEMI_ON(LAZY) ((LAZY) == 0 && KX_SEMI != 0)
+#ifndef KX_SEMI_UNI
+#define KX_SEMI_UNI 1   // strict kernels: the semi-strict schedule in the wave-uniform passes only (ntt_core_f64.hpp SEMIU; round 5)
+#endif
+#define KX_SEMIU_ON(LAZY) ((LAZY) == 0 && KX_SEMI == 0 && KX_SEMI_UNI != 0)
 #ifndef KX_STRICT_FOLD
 #define KX_STRICT_FOLD 1   // strict kernels (moduli above the lazy bound, up to 2^52): folded multiply-accumulate as well
 #endif
@@ -439,7 +443,7 @@ template <int LOGN, int LOGE, int LAZY, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, KX_SEMI_ON(LAZY)>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, KX_SEMI_ON(LAZY), 0, KX_SEMIU_ON(LAZY)>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;
@@ -635,8 +639,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
     // (strict kernels: the semi-strict forward schedule, f64_arith.hpp ct_bfly_semi -- plain twiddle loads, no PRE requests)
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY)>;               // mod-down transforms: centred input
-    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY)>;   // mod-up transforms (SKIP: canonical c_d as it is)
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY), 0, KX_SEMIU_ON(LAZY)>;               // mod-down transforms: centred input
+    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY), 0, KX_SEMIU_ON(LAZY)>;   // mod-up transforms (SKIP: canonical c_d as it is)
     constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
     // the strict kernels (moduli up to 2^52) fold their multiply-accumulate too (round 4; f64_arith.hpp mac_fold "strict tier": transform
     // output |x| <= p/2 + 2, accumulators <= 0.9p between terms) and reduce the accumulators once in front of the mod-down, whose
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(256) void k_ksh_finish(KsArgsX a, u32 rows) {
 template <int LAZY, bool SKIP>
 __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, false, 1>;
+    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;
     constexpr u32 NF = 2 * G::N;
     constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
@@ -1027,8 +1031,8 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
 template <int LAZY, bool SKIP>
 __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, 0, false, HX_FWD_PRIO, false, 1>;                 // mod-down transforms: centred input
-    using WU = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, false, 1>;     // mod-up transforms
+    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, 0, false, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;                 // mod-down transforms: centred input
+    using WU = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;     // mod-up transforms
     constexpr u32 NF = 2 * G::N;
     constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
     constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);

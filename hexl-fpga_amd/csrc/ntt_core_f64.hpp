@@ -284,9 +284,16 @@ __device__ __forceinline__ void hx_inv_prio() {
 // numbers (reduction schedule), table size and twiddle group indices of the FULL transform; `top` (wave-uniform) = which block. The
 // outer TOP stages are the caller's: a radix-2 step across the blocks on load / in a finishing pass (keyswitch_x.hip HALF kernels), the
 // same cut keyswitch_lat.hip makes in four (WgSubNtt).
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, bool SEMI = false, int TOP = 0>
+// SEMIU (strict kernels, round 5): the semi-strict schedule in the passes whose twiddles are WAVE-UNIFORM only (the first pass and every
+// pass with LO >= 6: for N = 16384 eight of the fourteen stages) -- there w and w/p come through the scalar cache, so the second table costs
+// no vector loads, no registers and does not disturb the per-lane passes' early twiddle requests (PRE), which is what made the all-passes
+// variant (SEMI) lose. The schedule is pass-local (f64_arith.hpp ct_bfly_semi: a pass starts from reduced values and its last stage
+// reduces everything), so strict and semi-strict passes mix freely.
+template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, bool SEMI = false, int TOP = 0,
+          bool SEMIU = false>
 struct WgNttF64 {
     static_assert(!SEMI || (LAZY == 0 && PRE == 0 && TF == 0), "semi-strict forward transforms: strict kernels, plain twiddle loads");
+    static_assert(!SEMIU || (LAZY == 0 && TF == 0 && !SEMI), "semi-strict uniform passes: strict kernels");
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
     static constexpr int FLOGN = LOGN + TOP;                      // log2 of the full transform
@@ -317,7 +324,8 @@ struct WgNttF64 {
             const u32 Gl = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             const u32 Gp = gfwd<PASS * LOGE + 1>(top, Gl);
             if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, FSHIFT>(v, Gp, w, m);
-            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT, 0, SEMI>(v, Gp, w, wp, m);
+            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT, 0,
+                                (SEMI || (SEMIU && (PASS == 0 || LO >= 6)))>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
                 constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;

@@ -449,7 +449,9 @@ static void test_strict_wide(uint64_t n, uint64_t p, bool adversarial) {
 // pass structure: passes of `loge` stages, the last one partial; inside a pass a butterfly's outputs are reduced only when the next
 // stage adds them (bit t/2 of the index clear), the last stage of every pass reduces everything
 static double g_semi_max = 0, g_semi_inner = 0;
-static void test_semi(uint64_t n, int loge, uint64_t p, bool adversarial) {
+// uni_only (round 5, ntt_core_f64.hpp SEMIU): the semi-strict schedule in the wave-uniform passes only -- the first pass and every pass whose
+// lanes of a wave share the twiddle group (LO = logn - (pass + 1) loge >= 6) --, plain strict butterflies in the others
+static void test_semi(uint64_t n, int loge, uint64_t p, bool adversarial, bool uni_only = false) {
     hxf::Mod m{(double)p, 1.0 / (double)p};
     std::vector<uint64_t> blk(4 * n);
     orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
@@ -467,9 +469,15 @@ static void test_semi(uint64_t n, int loge, uint64_t p, bool adversarial) {
     for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
         const int pass = (s - 1) / loge, u = (s - 1) % loge, K = pass == passes - 1 ? kl : loge;
         const bool last_in_pass = u == K - 1;
+        const bool semi_pass = !uni_only || (pass < passes - 1 && (pass == 0 || logn - (pass + 1) * loge >= 6));
         for (uint64_t i = 0; i < mm; ++i) {
             const double w = centre(roots[mm + i]), wp = w / (double)p;
             for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (!semi_pass) {
+                    hxf::ct_bfly(v[j], v[j + t], w, m);
+                    for (double q : {v[j], v[j + t]}) { const double a = q < 0 ? -q : q; if (a > g_semi_max) g_semi_max = a; }
+                    continue;
+                }
                 const bool added_next = last_in_pass || ((j & (t >> 1)) == 0);
                 {   // intermediates
                     const double h = v[j + t] * w, k = __builtin_rint(v[j + t] * wp), inner = __builtin_fma(-k, m.p, h);
@@ -668,6 +676,7 @@ int main() {
             for (int adv = 0; adv < 2; ++adv) {
                 test_semi(16384, 4, p, adv); test_semi(16384, 5, p, adv); test_semi(1024, 4, p, adv); test_semi(8192, 5, p, adv);
                 test_semi(4096, 4, p, adv); test_semi(2048, 4, p, adv);
+                test_semi(16384, 4, p, adv, true); test_semi(8192, 4, p, adv, true); test_semi(1024, 4, p, adv, true);   // strict keyswitch kernels (SEMIU)
             }
         }
         std::printf("semi-strict forward schedule (%d primes): max |x| after a stage = 2^%.3f, largest intermediate 2^%.3f (limit 2^53)\n",
