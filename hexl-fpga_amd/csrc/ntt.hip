@@ -35,6 +35,10 @@ constexpr int ntt_fwd_prio(int logn) { return logn == 11 ? 0 : HX_FWD_PRIO; }
 
 using namespace hx;
 
+#ifndef NTT_SEMI_UNI
+#define NTT_SEMI_UNI 1   // the SEMI kernel variants: semi-strict butterflies in the wave-uniform passes only (ntt_core_f64.hpp SEMIU; 0: in every pass)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Exact-arithmetic fast path. The Harvey kernels above must be replayed op for op only where that is observable:
 // out-of-range data, improper tables (benchmarks pass random ones), moduli >= 2^52. When q < 2^52, the tables
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), SEMI>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), (SEMI && !NTT_SEMI_UNI), 0, (SEMI && NTT_SEMI_UNI)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), SEMI>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), (SEMI && !NTT_SEMI_UNI), 0, (SEMI && NTT_SEMI_UNI)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -486,7 +490,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 }
 
 static bool semi_enabled() {
-    static const bool v = [] { const char* e = getenv("HEXL_NTT_SEMI"); return e && atoi(e) == 1; }();    // measured 2-4 % slower: off
+    // round 4's variant (semi-strict butterflies in EVERY pass: twice the per-lane twiddle loads) measured 2-4 % slower and was off; round 5's
+    // runs them in the wave-uniform passes only (NTT_SEMI_UNI, ntt_core_f64.hpp SEMIU: w/p through the scalar cache) and measures +3-4 %
+    // forward (q = 2^52 + 393217: 11.4 -> 11.75 M NTT/s at batch 1024, 12.6 -> 13.15 M at batch 4096, same box): on; HEXL_NTT_SEMI=0 turns it off
+    static const bool v = [] { const char* e = getenv("HEXL_NTT_SEMI"); return !(e && atoi(e) == 0); }();
     return v;
 }
 static bool fast_path_enabled() {
@@ -886,9 +893,8 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
             if (logn == 14 && period == 12) return launch_fwd_x<14, 4, 12>(ctx, x, batch, roots, precon, q, pr);
             if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, pr);
             if (period) return dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, pr);
-            // strict tier: the plain strict butterflies; HEXL_NTT_SEMI=1 selects the semi-strict forward schedule (f64_arith.hpp
-            // ct_bfly_semi) up to 2^52 (1 + 2^-20): bit-exact, 11 instead of 14 instructions per butterfly, but it reads the w/p table
-            // too and measured 11.2-11.8 M against 11.5-12.0 M forward NTT/s at batch 1024 (tools/experiments/README.md)
+            // strict tier: semi-strict butterflies (f64_arith.hpp ct_bfly_semi, 11 instead of 14 instructions) in the wave-uniform passes up to
+            // 2^52 (1 + 2^-20) -- SURVEY 8d's q = 2^52 + 393217 included --, the plain strict ones above and with HEXL_NTT_SEMI=0
             return semi_enabled() && (double)q <= hxf::SEMI_MAX_MODULUS ? dispatch_fwd_x<0, true>(logn, ctx, x, batch, roots, precon, q, pr)
                                                                         : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, pr);
         }
