@@ -578,7 +578,7 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
 int hx_launch_multiply_relinearize(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t batch) {
     if (!batch) return 0;
     if (!p->have_keys) return HEXL_E_NOKEYS;
-    if (!p->use_f64 || p->logn < 10 || p->logn > 14) return HEXL_E_BADARG;   // see hx_launch_mulrelin_x
+    if (!p->use_f64 || p->logn < 10 || p->logn > 15) return HEXL_E_BADARG;   // see hx_launch_mulrelin_x
     const size_t chunk = batch < ks_chunk_default(p) ? batch : ks_chunk_default(p);
     const size_t lane_words = chunk * scratch_words(p) * p->n;
     if (p->cap < chunk) {

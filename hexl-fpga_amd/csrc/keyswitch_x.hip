@@ -547,7 +547,8 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
         };
         W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m, typename W::NoHook(), request);
     } else {
-        W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m, typename W::NoHook(), typename W::NoHook(), top);   // |w| <= 2.14p
+        // (the w/p table -- read by the strict kernels' semi-strict passes only -- lies one FULL transform's worth of words behind w)
+        W::template forward<false, false>(v, lds, tid, tb, tb + (PRED ? 2 : 1) * G::N, m, typename W::NoHook(), typename W::NoHook(), top);   // |w| <= 2.14p
     }
 #if KX_EPI_PRIO
     __builtin_amdgcn_s_setprio(KX_EPI_PRIO - 1);
@@ -919,7 +920,9 @@ __device__ __forceinline__ void ksh_combine(double (&v)[G::E], const double* __r
     }
 }
 
-template <int LAZY>
+// FUSED (hexl_multiply_relinearize at N = 32768): t_target[d] is the product a_1[d] . b_1[d] of the operand limbs, formed block by block (the
+// product is element-wise in the NTT domain, so half h of it needs half h of the operands only); k_ksh_main forms the other two components
+template <int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1024, 4) void k_ksh_intt(KsArgsX a) {
     using G = Geom<14, 4>;
     using W = WgNttF64<14, 4, LAZY, 0, 0, 0, true, HX_FWD_PRIO, false, 1>;
@@ -938,12 +941,17 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_intt(KsArgsX a) {
         u32 toff = d * 4 * NF;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        const u64* src = a.t_target + size_t(row) * NF + h * G::N;
-        const u64 qd = (u64)md.m.p;
-        const u32 tB = u32(G::idxB(0, tid));
         double v[G::E];
+        if constexpr (FUSED) {
+            const size_t at = ((size_t(ib) * 2 + 1) * a.L + d) * NF + h * G::N;
+            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, md.m);
+        } else {
+            const u64* src = a.t_target + size_t(row) * NF + h * G::N;
+            const u64 qd = (u64)md.m.p;
+            const u32 tB = u32(G::idxB(0, tid));
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);    // canonical words as they are
+            for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);    // canonical words as they are
+        }
         W::template inverse<false>(v, ldsx, tid, tb + 2 * NF, tb + 3 * NF, md.m, md.sc, typename W::NoHook(), h);
         double* dst = a.csub + (size_t(row) * 2 + h) * G::N;
 #pragma unroll
@@ -1028,7 +1036,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
     }
 }
 
-template <int LAZY, bool SKIP>
+template <int LAZY, bool SKIP, bool FUSED = false>
 __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
     using G = Geom<14, 4>;
     using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, 0, false, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;                 // mod-down transforms: centred input
@@ -1050,8 +1058,16 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i -- this workgroup's block of it
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        mac_keys_first<G, LAZYFOLD, int(NF)>(acc0, acc1, v, a.t_target + (size_t(b) * L + i) * NF + h * G::N, key_row<G>(a, i, i) + h * G::N,
-                                             round_src(first), tid, m);
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
+            const size_t at = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
+            load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, m);                    // |x| <= 0.7 p, centred
+            mac_keys<G, false, 0, KX_PF, int(NF)>(acc0, acc1, v, key_row<G>(a, i, i) + h * G::N, round_src(first), tid, m);
+        } else {
+            mac_keys_first<G, LAZYFOLD, int(NF)>(acc0, acc1, v, a.t_target + (size_t(b) * L + i) * NF + h * G::N, key_row<G>(a, i, i) + h * G::N,
+                                                 round_src(first), tid, m);
+        }
     }
 #pragma unroll 1
     for (u32 it = first; it < L;) {
@@ -1080,8 +1096,9 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L) + G::N, tid, tb, m, h);
-        ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc0, a.result + ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, ldsx, tid, tb, md, bad,
-                                                nullptr, nullptr, nullptr, nullptr, h);
+        const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
+        if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP, 0, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
+        else ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
         const double* nxt = round_src(L + 1);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -1093,8 +1110,9 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
         ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L + 1) + G::N, tid, tb, m, h);
-        ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc1, a.result + ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N, ldsx, tid, tb, md, bad,
-                                                nullptr, nullptr, nullptr, nullptr, h);
+        const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
+        if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP, 0, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
+        else ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
     }
     hxf::report_range(bad, a.range_flag);
 }
@@ -1216,14 +1234,14 @@ static int run_chunk_x(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* e
 
 // one chunk at N = 32768 (k_ksh_* kernels: every transform as two 16384-point halves). Tiers: strict / period 3 only (a shorter period
 // is always valid); limbs of different tiers get a launch per tier like run_chunk_x.
-template <int LAZY, bool SKIP>
+template <int LAZY, bool SKIP, bool FUSED = false>
 static int launch_stage_h(hexl_ks_plan* p, const KsArgsX& a, int stage) {
     using G = Geom<14, 4>;
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
-            int rc = set_lds_x(k_ksh_intt<LAZY>, G::LDS_USED);
+            int rc = set_lds_x(k_ksh_intt<LAZY, FUSED>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksh_special<LAZY, SKIP>, G::LDS_USED);
-            if (!rc) rc = set_lds_x(k_ksh_main<LAZY, SKIP>, G::LDS_USED);
+            if (!rc) rc = set_lds_x(k_ksh_main<LAZY, SKIP, FUSED>, G::LDS_USED);
             return rc;
         }))
         return rc0;
@@ -1232,15 +1250,17 @@ static int launch_stage_h(hexl_ks_plan* p, const KsArgsX& a, int stage) {
         const u32 per_xcd = (items + 7) / 8, slots = ((u32)p->ctx->num_cu + 7) / 8;
         return dim3(8 * (per_xcd > slots ? slots : per_xcd));
     };
-    if (stage == 1) hipLaunchKernelGGL((k_ksh_intt<LAZY>), grid_for(a.nb * a.nsel * 2), dim3(G::T), G::LDS_USED, st, a);
+    if (stage == 1) hipLaunchKernelGGL((k_ksh_intt<LAZY, FUSED>), grid_for(a.nb * a.nsel * 2), dim3(G::T), G::LDS_USED, st, a);
     if (stage == 2) hipLaunchKernelGGL((k_ksh_special<LAZY, SKIP>), grid_for(a.nb * 2), dim3(G::T), G::LDS_USED, st, a);
-    if (stage == 4) hipLaunchKernelGGL((k_ksh_main<LAZY, SKIP>), dim3(a.nb * a.nsel * 2), dim3(G::T), G::LDS_USED, st, a);
+    if (stage == 4) hipLaunchKernelGGL((k_ksh_main<LAZY, SKIP, FUSED>), dim3(a.nb * a.nsel * 2), dim3(G::T), G::LDS_USED, st, a);
     return 0;
 }
+template <bool FUSED>
 static int launch_stage_h_tier(hexl_ks_plan* p, const KsArgsX& a, int stage, int tier, bool skip) {
-    if (!tier) return launch_stage_h<0, false>(p, a, stage);
-    return skip ? launch_stage_h<3, true>(p, a, stage) : launch_stage_h<3, false>(p, a, stage);
+    if (!tier) return launch_stage_h<0, false, FUSED>(p, a, stage);
+    return skip ? launch_stage_h<3, true, FUSED>(p, a, stage) : launch_stage_h<3, false, FUSED>(p, a, stage);
 }
+template <bool FUSED = false>
 static int run_chunk_h(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* ev) {
     hipStream_t st = p->cur;
     const u32 L = a.L;
@@ -1252,7 +1272,7 @@ static int run_chunk_h(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* e
             a.nsel = 0; a.selmap = 0;
             for (u32 i = i0; i < L; ++i)
                 if (!done[i] && tier_of(i) == tier_of(i0)) { done[i] = true; a.selmap |= (unsigned long long)i << (4 * a.nsel++); }
-            if (int rc = launch_stage_h_tier(p, a, stage, tier_of(i0), p->x_skip)) return rc;
+            if (int rc = launch_stage_h_tier<FUSED>(p, a, stage, tier_of(i0), p->x_skip)) return rc;
         }
         return 0;
     };
@@ -1264,7 +1284,7 @@ static int run_chunk_h(hexl_ks_plan* p, KsArgsX a, int stage_mask, hipEvent_t* e
     if (ev) HX_CHECK(hipEventRecord(ev[1], st));
     if (stage_mask & 2) {
         a.nsel = L; a.selmap = 0xFEDCBA9876543210ull;
-        if (int rc = launch_stage_h_tier(p, a, 2, tier_of(a.K - 1), p->x_skip)) return rc;
+        if (int rc = launch_stage_h_tier<FUSED>(p, a, 2, tier_of(a.K - 1), p->x_skip)) return rc;
         hipLaunchKernelGGL((k_ksh_finish<1>), dim3((1u << 14) / 256, a.nb * 2), dim3(256), 0, st, a, a.nb * 2);
     }
     if (ev) HX_CHECK(hipEventRecord(ev[2], st));
@@ -1356,6 +1376,9 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
     a.mods = p->d_mods_f64; a.tables = p->d_tables_f64; a.keys = p->d_keys_x;
     a.c = (double*)p->cur_scratch;
     a.s = a.c + p->cap * L * n;
+    a.csub = a.s + p->cap * 2 * n;                                  // (N = 32768 only)
+    a.ssub = a.csub + p->cap * L * n;
+    a.nsel = (u32)L; a.selmap = 0xFEDCBA9876543210ull;
     a.t_target = nullptr; a.result = d_out;
     a.L = (u32)L; a.K = p->K; a.nb = (u32)nb;
     a.mul_a = d_a; a.mul_b = d_b;
@@ -1369,6 +1392,7 @@ int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64*
         case 12: return mulrelin_for<12>(p, a);
         case 13: return mulrelin_for<13>(p, a);
         case 14: return mulrelin_for<14>(p, a);
+        case 15: return run_chunk_h<true>(p, a, 7, nullptr);         // every transform as two 16384-point halves (k_ksh_*)
         default: return HEXL_E_BADARG;
     }
 }

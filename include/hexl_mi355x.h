@@ -115,7 +115,7 @@ int hexl_ks_range_check(hexl_ks_plan* plan);
  *   d_a, d_b [batch][2][L][n] (the DyadicMultiply operand layout with n_moduli = L, words < q_i);
  *   d_out    [batch][2][L][n] is WRITTEN with (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1), i.e. what
  *   DyadicMultiply followed by KeySwitch(result = components 0..1, t_target = component 2) leaves -- but the
- *   three-component product never exists in memory. n = 1024 ... 16384 and moduli < 2^52 only (else HEXL_E_BADARG).
+ *   three-component product never exists in memory. n = 1024 ... 32768 and moduli < 2^52 only (else HEXL_E_BADARG).
  *   d_out must not overlap d_a or d_b (component 0 is stored before component 1's operands are read): HEXL_E_BADARG. */
 int hexl_multiply_relinearize(hexl_ks_plan* plan, uint64_t* d_out, const uint64_t* d_a,
                               const uint64_t* d_b, size_t batch);

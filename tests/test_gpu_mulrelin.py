@@ -29,7 +29,9 @@ def composed(orc, case, a, b):
                                              (8192, 3, 4, 70, False), (1024, 2, 3, 300, False), (8192, 2, 3, 3, True),
                                              (2048, 2, 3, 150, False), (4096, 3, 4, 120, False), (4096, 2, 3, 4, True),
                                              # round 5: limbs of different tiers (one launch per tier group, keyswitch_x.hip run_chunk_x)
-                                             (16384, 6, 7, 40, "seal"), (16384, 3, 4, 5, "ladder"), (4096, 3, 4, 60, "seal")])
+                                             (16384, 6, 7, 40, "seal"), (16384, 3, 4, 5, "ladder"), (4096, 3, 4, 60, "seal"),
+                                             # ... and N = 32768: every transform as two 16384-point halves (k_ksh_*<..., FUSED>)
+                                             (32768, 3, 4, 5, False), (32768, 2, 3, 130, False), (32768, 3, 4, 4, True), (32768, 3, 4, 4, "seal")])
 def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, n, L, K, nb, strict):
     moduli = primes_below(orc, K, 1 << 52, n) if strict is True else None      # just below 2^52: the strict FP64 kernels
     if strict == "seal":
@@ -56,8 +58,8 @@ def test_vs_composition_of_the_oracles(hx, ctx, dev, orc, n, L, K, nb, strict):
 
 
 def test_rejects_what_it_does_not_cover(hx, ctx, dev, orc):
-    n = 32768                                                    # beyond the slot-major pipeline
-    case = KsCase(orc, n, 2, 3, seed=1)
+    n = 4096                                                     # moduli >= 2^52: the integer kernels have no fused pass
+    case = KsCase(orc, n, 2, 3, seed=1, bits=55)
     plan = hx.KeySwitchPlan(ctx, n, 2, 3, 3, 2, case.moduli, case.modswitch)
     plan.set_keys(case.keys)
     import torch
