@@ -1365,8 +1365,7 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
 // fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry).
 // Where the partial pass leaves a lane at most four adjacent words (N = 1024, 8192, 16384) the operand limbs are read straight at
 // the transforms' B positions; N = 2048 / 4096 read them in A order and go through LDS (load_product_to_B, ksx_down_round).
-// (N = 32768 has no slot-major pipeline at all -- 64 registers of polynomial + 128 of accumulators do not fit a 1024-thread
-// workgroup.)
+// (N = 32768: the half-transform kernels k_ksh_*<..., FUSED>, hx_launch_mulrelin_x below.)
 template <int LOGN>
 static int mulrelin_for(hexl_ks_plan* p, const KsArgsX& a) { return run_chunk_x<LOGN, 4, true>(p, a, 7, nullptr); }
 int hx_launch_mulrelin_x(hexl_ks_plan* p, u64* d_out, const u64* d_a, const u64* d_b, size_t nb) {
