@@ -67,12 +67,13 @@ NTT_BITS_INTEGER = 59               # a modulus only the integer Harvey kernels 
 NTT_Q_REFBENCH = 136314881          # benchmark/bench_fwd_ntt.cpp:28-42, bench_inv_ntt.cpp: RANDOM roots / precons / inv_n -> integer butterflies
 
 
-def time_ntt(hx, ctx, orc_mod, dev, batch, iters, barrier=None, max_over_ranks=None, world=1, q=None, random_tables=False):
+def time_ntt(hx, ctx, orc_mod, dev, batch, iters, barrier=None, max_over_ranks=None, world=1, q=None, random_tables=False, n=None):
     """BASELINE config 2 shape (fwd / inv NTT, N = 16384, one prime, `batch` polynomials per launch) on EVERY rank:
     per-rank device time from HIP events, and -- BASELINE's second metric -- the whole-job rate = world x batch x iters /
     the slowest rank's wall time between two barriers. `random_tables`: the reference benchmark's own workload (uniform random
     words below q as roots, precons, inv_n, inv_n_w: not Shoup tables, so every polynomial takes the integer butterflies)."""
     import torch
+    N = n or globals()["N"]
     q = q or orc_mod.primes(1, 51, N)[0]
     if random_tables:
         rng = np.random.default_rng(7)
@@ -726,6 +727,8 @@ def main():
             extra["ntt_N16384_batch1024_q_2p52_plus_393217_strict_fp64"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=NTT_Q_SURVEY)
             extra["ntt_N16384_batch1024_59bit_prime_integer_kernels"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=orc_mod.primes(1, NTT_BITS_INTEGER, N)[0])
             extra["ntt_N16384_batch1024_refbench_random_tables"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=NTT_Q_REFBENCH, random_tables=True)
+            # beyond the reference's envelope: N = 32768 as two 16384-point sub-transforms per polynomial (ntt.hip k_ntt_fwd_h / k_ntt_inv_h)
+            extra["ntt_N32768_batch512_two_sub_transforms"] = time_ntt(hx, ctx, orc_mod, dev, 512, 60, n=32768)
             extra["cxx_api_end_to_end"] = cxx_api_end_to_end(6)
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
             def other_shape(Lx, Kx, moduli=None, n=N):

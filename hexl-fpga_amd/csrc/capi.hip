@@ -59,6 +59,7 @@ extern "C" int hexl_ctx_destroy(hexl_ctx* c) {
     if (c->d_shared) (void)hipFree(c->d_shared);
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->d_ntt_tab) (void)hipFree(c->d_ntt_tab);
+    if (c->d_ntt_redo) (void)hipFree(c->d_ntt_redo);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_lone) (void)hipHostFree(c->h_lone);
     if (c->h_ntt_hint) (void)hipHostFree(c->h_ntt_hint);

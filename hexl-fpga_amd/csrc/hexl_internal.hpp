@@ -56,6 +56,7 @@ struct hexl_ctx {
     hipStream_t s_up = nullptr, s_down = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     void* d_meta = nullptr;   size_t d_meta_bytes = 0;     // dyadic per-(item,modulus) constants
+    void* d_ntt_redo = nullptr; size_t d_ntt_redo_bytes = 0; // N = 32768 standalone NTT: polynomials left to the integer butterflies (ntt.hip k_ntt_redo_*)
     void* d_ntt_tab = nullptr; size_t d_ntt_tab_bytes = 0;  // standalone NTT fast path: violation counters + derived double tables
     uint32_t ntt_seq = 0;                                   // launches so far (selects the violation counter)
     // "these tables are not Shoup tables" hints from the fast-path kernels to the host (ntt.hip NttHint): four pinned words

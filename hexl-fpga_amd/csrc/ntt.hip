@@ -75,6 +75,7 @@ struct NttPrep {
     // counter in words 0 and 1 (ready: slices done in the low half, slices with a bad entry in the high half): ring[x * NTT_RING_STRIDE + k]
     u32* ring; u32* ring_later;
     u32 n, fused;
+    u32* redo;                           // N = 32768 half-transform launches: [0] how many polynomials the integer butterflies must redo, [1 ...] which
 };
 
 constexpr u32 NTT_RING_STRIDE = 32;       // 128 bytes: the XCDs poll and count in different cache lines
@@ -86,6 +87,7 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     if (i == 0) {
         pr.w[0] = 0.0;
         *pr.viol_later = 0;
+        if (pr.redo) *pr.redo = 0;
         for (u32 x = 0; x < 8; ++x)
             for (u32 k = 0; k < 3; ++k) pr.ring_later[x * NTT_RING_STRIDE + k] = 0;
         return;
@@ -489,6 +491,193 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     }
 }
 
+// N = 32768 (beyond the reference's envelope): one polynomial = TWO 16384-point sub-transforms (round 5, the cut the slot-major keyswitch
+// makes, keyswitch_x.hip k_ksh_*). 64 registers of polynomial per thread leave a 1024-thread workgroup no room for anything else, and
+// 256 KiB do not fit the CU's LDS: k_ntt_fwd_x / k_ntt_inv_x<15, 5> exchange in half-size rounds, one workgroup per polynomial, no
+// prefetch. Here the outermost stage is a radix-2 step ACROSS the two halves of the polynomial -- on load (forward: global stage 1, one
+// twiddle) or behind the sub-transforms (inverse: the last stage, n^-1 folded in) -- and the other fourteen are two sub-transforms with
+// the geometry, LDS footprint and register budget of the N = 16384 kernels (WgNttF64<14, 4, ..., TOP = 1>: stage numbers, reduction
+// schedule and twiddle indices of the full transform). The transform is in place, so ONE persistent workgroup does both halves of a
+// polynomial: the half that is not being transformed waits in the registers the N = 16384 kernels prefetch into.
+// Same butterflies as the monolithic transform, canonical results: bit-identical.
+// Polynomials that fail the range vote are only NOTED here (prep.redo: a counter and a list; nothing of theirs has been stored) and redone
+// by the integer butterflies in a launch of their own right behind this one (k_ntt_redo_*), which also takes the whole batch when the
+// tables are not Shoup tables. With the out-of-line fallback CALLED from these kernels -- inside the walk or behind it -- the allocator
+// parks the second sub-transform's results in scratch on the fast path (inverse: 5.1 M against 6.2 M NTT/s).
+__device__ __forceinline__ void ntt_note_redo(const NttPrep& prep, u32 p, int tid) {
+    if (tid == 0) prep.redo[1 + atomicAdd(prep.redo, 1u)] = p;
+}
+template <int LAZY, bool SEMI = false>
+__global__ __launch_bounds__(1024) void k_ntt_fwd_h(u64* __restrict__ x, const u64* __restrict__ roots, const u64* __restrict__ precon,
+                                                    u64 q, NttPrep prep, u32 batch, NttHint hint) {
+    using G = Geom<14, 4>;
+    constexpr int FS = LAZY != 0 ? 1 : 0;
+    using W = WgNttF64<14, 4, LAZY, 0, 0, FS, false, ntt_fwd_prio(14), (SEMI && !NTT_SEMI_UNI), 1, (SEMI && NTT_SEMI_UNI)>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u64 limit = fast_path_limit<LAZY>(q, true);
+    const Mod m{(double)q, 1.0 / (double)q};
+    const double *w, *wp;
+    const bool bad_tables = ntt_tables_ready<G::T>(prep, roots, precon, q, w, wp);
+    if (bad_tables) {                                                           // see k_ntt_fwd_p; k_ntt_redo_fwd does the batch
+        if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
+        return;
+    }
+    RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
+    const double W1 = ((ctw_t)w)[1];                                            // global stage 1: one twiddle
+    constexpr bool red = LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, FS);
+#pragma unroll 1
+    for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u64* px = x + size_t(p) * 2 * G::N;
+        bool out_of_range = false;
+        double u[G::E], v[G::E];
+        {
+            u64 lo[G::E], hi[G::E];
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) lo[r] = (px + G::idxA(r, 0))[u32(tid)];
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) hi[r] = (px + G::N + G::idxA(r, 0))[u32(tid)];
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) {
+                out_of_range |= (lo[r] >= limit) | (hi[r] >= limit);
+                const double a = fast_path_input<LAZY>(lo[r], m);
+                const double t = hxf::mul_mod(fast_path_input<LAZY>(hi[r], m), W1, m);
+                u[r] = red ? hxf::reduce(a + t, m) : a + t;
+                v[r] = red ? hxf::reduce(a - t, m) : a - t;
+            }
+        }
+        vote.cast(out_of_range);
+        W::template forward<false>(u, reinterpret_cast<double*>(lds), tid, w, wp, m, typename W::NoHook(), typename W::NoHook(), 0u);
+        if (vote.result(tid)) {                                                  // before anything is stored
+            ntt_note_redo(prep, p, tid);
+            continue;
+        }
+        // (strict tier: the conversion that does not assume 52 bits for every modulus, see k_ntt_inv_h)
+        auto store = [&](const double (&f)[G::E], u64* to) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) to[G::idxB(r, tid)] = LAZY == 0 ? hxf::from_f64_53(hxf::lift(f[r], m)) : hxf::from_f64(hxf::lift(f[r], m));
+        };
+        store(u, px);
+        W::template forward<false>(v, reinterpret_cast<double*>(lds), tid, w, wp, m, typename W::NoHook(), typename W::NoHook(), 1u);
+        store(v, px + G::N);
+    }
+}
+
+template <int LAZY>
+__global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u64* __restrict__ iroots, const u64* __restrict__ iprecon,
+                                                    u64 q, NttPrep prep, hxf::InvScale sc, u32 batch, NttHint hint) {
+    using G = Geom<14, 4>;
+    using W = WgNttF64<14, 4, LAZY, 0, 0, 0, true, HX_FWD_PRIO, false, 1>;      // no w/p table
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u64 limit = fast_path_limit<LAZY>(q, false);
+    const Mod m{(double)q, 1.0 / (double)q};
+    const double *w, *wp;
+    const bool bad_tables = ntt_tables_ready<G::T>(prep, iroots, iprecon, q, w, wp);
+    if (bad_tables) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
+        return;
+    }
+    RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
+    // block 1 of a polynomial is requested inside the transform of block 0 (where k_ntt_inv_p requests its next polynomial), block 0 of the
+    // NEXT polynomial behind the second transform, pair by pair between the stores; two votes per polynomial, nothing is stored before the
+    // second
+    u64 raw[G::E];
+    {
+        const u64* p0 = x + size_t(blockIdx.x) * 2 * G::N;
+        const u32 tB = u32(G::idxB(0, threadIdx.x));
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
+    }
+#pragma unroll 1
+    for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        u64* px = x + size_t(p) * 2 * G::N;
+        const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;                // (last round: a harmless re-read)
+        const u64* pnx = x + size_t(pn) * 2 * G::N;
+        const u32 tB = u32(G::idxB(0, tid));
+        auto request = [&](const u64* from) {
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) raw[r] = (from + G::idxB(r, 0))[tB];
+        };
+        bool out_of_range = false;
+        double u[G::E], v[G::E];
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            out_of_range |= raw[r] >= limit;
+            u[r] = fast_path_input<LAZY>(raw[r], m);
+        }
+        vote.cast(out_of_range);
+        W::template inverse<false>(u, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, [&] { request(px + G::N); }, 0u);
+        bool slow = vote.result(tid);
+        if (!slow) {
+            out_of_range = false;
+#pragma unroll
+            for (int r = 0; r < G::E; ++r) {
+                out_of_range |= raw[r] >= limit;
+                v[r] = fast_path_input<LAZY>(raw[r], m);
+            }
+            vote.cast(out_of_range);
+            W::template inverse<false>(v, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, typename W::NoHook(), 1u);
+            slow = vote.result(tid);
+        }
+        if (slow) {
+            ntt_note_redo(prep, p, tid);
+            request(pnx);
+            continue;
+        }
+        // the inverse's last stage across the halves, n^-1 folded in (inv_stages_f64's fused stage on register pairs), pair by pair: a pair
+        // is stored and its registers take the next polynomial's word -- all sixteen requests up front, beside 64 live registers of
+        // results, had the compiler park the arriving words in scratch one by one (a wait per word)
+        // (strict tier: the conversion that does not assume 52 bits for every modulus -- a wave-uniform choice between two copies of this
+        // loop, as in fast_path_store, had the allocator park the results in scratch in front of the branch)
+#pragma unroll
+        for (int r = 0; r < G::E; ++r) {
+            double pr2[2] = {u[r], v[r]};
+            inv_stages_f64<2, 0, 1, 14, 15, true, 3, true, 0, true>(pr2, 0u, w, wp, m, sc);
+            const double c0 = hxf::lift(pr2[0], m), c1 = hxf::lift(pr2[1], m);
+            (px + G::idxA(r, 0))[u32(tid)] = LAZY == 0 ? hxf::from_f64_53(c0) : hxf::from_f64(c0);
+            (px + G::N + G::idxA(r, 0))[u32(tid)] = LAZY == 0 ? hxf::from_f64_53(c1) : hxf::from_f64(c1);
+            raw[r] = (pnx + G::idxB(r, 0))[tB];
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// the integer butterflies for what the half-transform kernels left: the noted polynomials, or the whole batch under tables that are not
+// Shoup tables (one workgroup per CU at most; an empty list costs a dispatch)
+__global__ __launch_bounds__(1024) void k_ntt_redo_fwd(u64* __restrict__ x, const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q,
+                                                       NttPrep prep, u32 batch) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const bool all = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const u32 n = all ? batch : __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u32 p = all ? i : prep.redo[1 + i];
+        slow_fwd<15, 5>(x + (size_t(p) << 15), lds, roots, precon, q);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_ntt_redo_inv(u64* __restrict__ x, const u64* __restrict__ iroots, const u64* __restrict__ iprecon, u64 q,
+                                                       u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, NttPrep prep, u32 batch) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const bool all = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const u32 n = all ? batch : __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u32 p = all ? i : prep.redo[1 + i];
+        slow_inv<15, 5>(x + (size_t(p) << 15), lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        __syncthreads();
+    }
+}
+
+// HEXL_NTT_HALVES=0: N = 32768 back on the monolithic half-size-exchange kernels (A/B)
+static bool halves_enabled() {
+    static const bool v = [] { const char* e = getenv("HEXL_NTT_HALVES"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
 static bool semi_enabled() {
     // round 4's variant (semi-strict butterflies in EVERY pass: twice the per-lane twiddle loads) measured 2-4 % slower and was off; round 5's
     // runs them in the wave-uniform passes only (NTT_SEMI_UNI, ntt_core_f64.hpp SEMIU: w/p through the scalar cache) and measures +3-4 %
@@ -530,6 +719,7 @@ static int reserve_tables(hexl_ctx* ctx, u64 n, NttPrep* pr) {
     pr->ring_later = counters + 64 + 8 * NTT_RING_STRIDE * ((seq + 32) & 63);
     pr->n = (u32)n;
     pr->fused = 0;
+    pr->redo = nullptr;
     return 0;
 }
 // the preparation as a launch of its own, in front of a transform kernel that does not do it itself
@@ -815,6 +1005,52 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     return (int)hipGetLastError();
 }
 
+static int reserve_redo(hexl_ctx* ctx, size_t batch, NttPrep* pr) {
+    int rc = hx_reserve_device(ctx, &ctx->d_ntt_redo, &ctx->d_ntt_redo_bytes, (batch + 1) * sizeof(u32));
+    pr->redo = (u32*)ctx->d_ntt_redo;
+    pr->fused = 0;
+    return rc;
+}
+template <int LAZY, bool SEMI = false>
+static int launch_fwd_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q, NttPrep pr) {
+    using G = Geom<14, 4>;
+    constexpr size_t LDS = G::LDS_USED + RangeVote::BYTES, LDS_INT = Geom<15, 5>::LDS_USED;
+    static PerDeviceOnce once;
+    if (int rc = once.run(ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_h<LAZY, SEMI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INT));
+            return 0;
+        }))
+        return rc;
+    if (int rc = reserve_redo(ctx, batch, &pr)) return rc;
+    if (int rc = launch_prepare(ctx, roots, precon, q, pr)) return rc;           // (also zeroes the redo counter)
+    const unsigned grid = (unsigned)(batch < (size_t)ctx->num_cu ? batch : (size_t)ctx->num_cu);
+    hipLaunchKernelGGL((k_ntt_fwd_h<LAZY, SEMI>), dim3(grid), dim3(G::T), LDS, ctx->stream, x, roots, precon, q, pr, (u32)batch,
+                       NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+    hipLaunchKernelGGL(k_ntt_redo_fwd, dim3(grid), dim3(G::T), LDS_INT, ctx->stream, x, roots, precon, q, pr, (u32)batch);
+    return (int)hipGetLastError();
+}
+template <int LAZY>
+static int launch_inv_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const u64* ip, u64 q, u64 a, u64 ap, u64 b, u64 bp, NttPrep pr,
+                        hxf::InvScale sc) {
+    using G = Geom<14, 4>;
+    constexpr size_t LDS = G::LDS_USED + RangeVote::BYTES, LDS_INT = Geom<15, 5>::LDS_USED;
+    static PerDeviceOnce once;
+    if (int rc = once.run(ctx->device, [] {
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_h<LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INT));
+            return 0;
+        }))
+        return rc;
+    if (int rc = reserve_redo(ctx, batch, &pr)) return rc;
+    if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
+    const unsigned grid = (unsigned)(batch < (size_t)ctx->num_cu ? batch : (size_t)ctx->num_cu);
+    hipLaunchKernelGGL((k_ntt_inv_h<LAZY>), dim3(grid), dim3(G::T), LDS, ctx->stream, x, ir, ip, q, pr, sc, (u32)batch,
+                       NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+    hipLaunchKernelGGL(k_ntt_redo_inv, dim3(grid), dim3(G::T), LDS_INT, ctx->stream, x, ir, ip, q, a, ap, b, bp, pr, (u32)batch);
+    return (int)hipGetLastError();
+}
+
 // FP64 transforms of N = 2048 .. 8192: 16 coefficients per thread where that measured faster than 32 (twice the waves
 // per CU, but a different run length per lane in the B-order access): forward N = 2048 (+17 %) and 8192 (+16 %), inverse
 // N = 2048 (+12 %); N = 4096 lost 16 % both ways, the inverse at 8192 11 % (tools/ntt_n_sweep.py).
@@ -836,7 +1072,8 @@ static int dispatch_fwd_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64
         case 13: return small_e16(13, true) ? launch_fwd_x<13, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr)
                                    : launch_fwd_x<13, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);
         case 14: return launch_fwd_x<14, 4, LAZY, SEMI>(c, x, batch, r, p, q, pr);
-        case 15: return launch_fwd_x<15, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);    // beyond the reference: half-size exchanges
+        case 15: return halves_enabled() ? launch_fwd_h<LAZY, SEMI>(c, x, batch, r, p, q, pr)       // beyond the reference: two sub-transforms
+                                         : launch_fwd_x<15, 5, LAZY, SEMI>(c, x, batch, r, p, q, pr);   // (half-size exchanges)
         default: return HEXL_E_BADARG;
     }
 }
@@ -852,7 +1089,8 @@ static int dispatch_inv_x(int logn, hexl_ctx* c, u64* x, size_t batch, const u64
         case 13: return small_e16(13, false) ? launch_inv_x<13, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc)
                                    : launch_inv_x<13, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
         case 14: return launch_inv_x<14, 4, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
-        case 15: return launch_inv_x<15, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
+        case 15: return halves_enabled() ? launch_inv_h<LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc)
+                                         : launch_inv_x<15, 5, LAZY>(c, x, batch, r, p, q, a, ap, b, bp, pr, sc);
         default: return HEXL_E_BADARG;
     }
 }

@@ -176,9 +176,9 @@ def test_full_batch_roundtrip_and_linearity(hx, ctx, dev, orc):
 
 @pytest.mark.parametrize("bits", [51, 30, 55])
 def test_n32768_beyond_the_reference_envelope(hx, ctx, dev, orc, bits):
-    """N = 32768: the polynomial does not fit the CU's LDS, every re-deal runs in two half-size rounds
-    (ntt_core.hpp: redeal_half). 51/30-bit primes take the exact FP64 path, 55-bit the integer butterflies; ALL_MAX data
-    forces the per-polynomial integer fallback of the fast-path kernel."""
+    """N = 32768: 51/30-bit primes take the exact FP64 path (round 5: two 16384-point sub-transforms per polynomial,
+    ntt.hip k_ntt_fwd_h / k_ntt_inv_h), 55-bit the integer butterflies (the polynomial does not fit the CU's LDS: every re-deal runs in
+    two half-size rounds, ntt_core.hpp redeal_half); ALL_MAX data forces the per-polynomial integer fallback (k_ntt_redo_*)."""
     n = 32768
     q = orc.primes(1, bits, n)[0]
     tb = orc.HexlTables(n, q)
@@ -195,8 +195,56 @@ def test_n32768_beyond_the_reference_envelope(hx, ctx, dev, orc, bits):
     assert np.array_equal(hx.to_u64(d), orc.ntt_inv(ys, tb))
 
 
-@pytest.mark.parametrize("env", [{"HEXL_NTT_E16": "7"}, {"HEXL_NTT_E16": "0"}, {"HEXL_NTT_INT": "1"}, {"HEXL_NTT_PERSIST": "0"}],
-                         ids=["fp64_16_per_thread", "fp64_32_per_thread", "integer_butterflies", "one_workgroup_per_polynomial"])
+def _largest_prime_below(orc, top, n):
+    v = ((top - 1) // (2 * n)) * (2 * n) + 1
+    while not orc.orc().orc_is_prime(v):
+        v -= 2 * n
+    return v
+
+
+@pytest.mark.parametrize("tier", ["lazy_51bit", "lazy_30bit", "strict_largest_below_2p52", "strict_2p52_plus_393217"])
+def test_n32768_as_two_sub_transforms(hx, ctx, dev, orc, tier):
+    """N = 32768 on the persistent half-transform kernels (ntt.hip k_ntt_fwd_h / k_ntt_inv_h, round 5): a radix-2 step across the halves
+    plus two 16384-point sub-transforms per polynomial. A batch that makes every workgroup walk several polynomials, in both lazy and
+    both strict arithmetic shapes; every fifth polynomial carries one word outside the fast path's range -- in the lower or the upper
+    half -- and takes the integer fallback inside the same launch; random (non-Shoup) tables take the integer butterflies for the
+    whole batch; all bit-exact against the oracle's op-for-op replay, plus the round trip at full batch."""
+    n = 32768
+    q = {"lazy_51bit": lambda: orc.primes(1, 51, n)[0], "lazy_30bit": lambda: orc.primes(1, 30, n)[0],
+         "strict_largest_below_2p52": lambda: _largest_prime_below(orc, 1 << 52, n),
+         "strict_2p52_plus_393217": lambda: 4503599627763713}[tier]()
+    assert orc.orc().orc_is_prime(q) and q % (2 * n) == 1
+    t = orc.HexlTables(n, q)
+    batch = 700
+    base = np.stack([orc.splitmix(n, 170 + b, q) for b in range(4)])
+    base[3, :4] = np.array([q - 1, 0, 1, q // 2], dtype=np.uint64)
+    base[3, n // 2:n // 2 + 4] = np.array([q - 1, q - 2, 0, q // 2 + 1], dtype=np.uint64)
+    x = base[np.arange(batch) % 4].copy()
+    odd = np.arange(2, batch, 5)
+    x[odd, (odd * 40503) % n] = np.uint64((1 << 63) + 11) + odd.astype(np.uint64)
+    assert ((odd * 40503) % n < n // 2).any() and ((odd * 40503) % n >= n // 2).any()
+    for fwd in (True, False):
+        got = (run_fwd if fwd else run_inv)(hx, ctx, dev, x, t)
+        ref4 = (orc.ntt_fwd if fwd else orc.ntt_inv)(base, t)
+        clean = np.setdiff1d(np.arange(batch), odd)
+        assert (got[clean] == ref4[clean % 4]).all(), "canonical polynomials"
+        sample = odd[:: max(1, len(odd) // 8)]
+        want = (orc.ntt_fwd if fwd else orc.ntt_inv)(x[sample], t)
+        assert np.array_equal(got[sample], want), "polynomials with out-of-range words"
+    y = run_inv(hx, ctx, dev, run_fwd(hx, ctx, dev, x[clean], t), t)
+    assert np.array_equal(y, x[clean])
+    if tier == "lazy_30bit":
+        rnd = orc.HexlTables(n, q)
+        rng = np.random.default_rng(5)
+        for arr in (rnd.roots, rnd.precon, rnd.inv_roots, rnd.inv_precon):
+            arr[:] = rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)
+        small = x[:300]
+        assert np.array_equal(run_fwd(hx, ctx, dev, small, rnd)[::37], orc.ntt_fwd(small[::37], rnd))
+        assert np.array_equal(run_inv(hx, ctx, dev, small, rnd)[::37], orc.ntt_inv(small[::37], rnd))
+
+
+@pytest.mark.parametrize("env", [{"HEXL_NTT_E16": "7"}, {"HEXL_NTT_E16": "0"}, {"HEXL_NTT_INT": "1"}, {"HEXL_NTT_PERSIST": "0"}, {"HEXL_NTT_HALVES": "0"}],
+                         ids=["fp64_16_per_thread", "fp64_32_per_thread", "integer_butterflies", "one_workgroup_per_polynomial", "n32768_half_size_exchanges"])
 def test_alternative_geometries_agree_with_the_oracle(env):
     """the kernel variants the defaults do not select at some ring dimension (ntt.hip small_e16, HEXL_NTT_INT,
     HEXL_NTT_PERSIST; knobs are read once per process, hence a child process): N = 2048 .. 16384, batches large
@@ -212,7 +260,8 @@ sys.path[:0] = [%r, %r, %r]
 import numpy as np, torch, hexl_fpga_amd as hx, orc
 dev = torch.device("cuda:0"); ctx = hx.Context(0)
 ok = True
-for n in (2048, 4096, 8192, 16384):
+import os
+for n in ((32768,) if os.environ.get("HEXL_NTT_HALVES") else (2048, 4096, 8192, 16384)):
     q = orc.primes(2, 51, n)[1]
     t = orc.HexlTables(n, q)
     x = np.stack([orc.splitmix(n, 7 + b, q) for b in range(4)])
