@@ -356,6 +356,21 @@ struct RangeVote {
     }
 };
 
+// Fast kernels WITHOUT a fallback of their own (ntt_inv_redo below, the N = 32768 half-transform kernels): a polynomial that fails the vote
+// is only noted -- nothing of it has been stored -- and redone by the integer butterflies in a launch of its own behind the fast kernel
+// (k_ntt_redo_*), which also takes the whole batch when the tables are not Shoup tables.
+__device__ __forceinline__ void ntt_note_redo(const NttPrep& prep, u32 p, int tid) {
+    if (tid == 0) prep.redo[1 + atomicAdd(prep.redo, 1u)] = p;
+}
+// Which inverse kernels do that: the strict-tier kernel at N = 16384. With the out-of-line fallback CALLED from it the allocator parks six of
+// the sixteen prefetched words of the next polynomial in scratch -- a wait for them in the middle of the transform: 11.3 M against 12.0 M
+// inverse NTT/s at q = 2^52 + 393217, batch 1024, 10.4 M against 11.9 M at batch 4096 with the fallback compiled out (round 5; the lazy
+// kernels and the forward ones spill around the call only and measure the same either way, so they keep the call and save the dispatch).
+#ifndef HX_NTT_INV_REDO
+#define HX_NTT_INV_REDO 1   // 0: A/B variant with the call inside (tools/build_variant.sh)
+#endif
+template <int LOGN, int LAZY> constexpr bool ntt_inv_redo = (HX_NTT_INV_REDO && LOGN == 14 && LAZY == 0);
+
 // Persistent variants (the default fast path): one workgroup per CU walks the batch, and the NEXT polynomial's words
 // are requested into 2 E spare registers at the very start of the current transform. A lone 1024-thread workgroup per
 // CU otherwise waits ~5 us for its 128 KiB input before every ~13 us transform (tools/ntt_timeline.hip) and pays the
@@ -445,13 +460,16 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
     }
     const double *w, *wp;
     const bool bad_tables = ntt_tables_ready<G::T>(prep, iroots, iprecon, q, w, wp);
+    constexpr bool REDO = ntt_inv_redo<LOGN, LAZY>;
     if (bad_tables) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
 #if !HX_NTT_NO_SLOW
+        if constexpr (!REDO) {
 #pragma unroll 1
-        for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
-            slow_inv<LOGN, LOGE>(x + size_t(p) * G::N, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
-            __syncthreads();
+            for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
+                slow_inv<LOGN, LOGE>(x + size_t(p) * G::N, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+                __syncthreads();
+            }
         }
 #endif
         return;
@@ -482,6 +500,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         const bool slow = vote.result(tid);
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
+        } else if constexpr (REDO) {
+            ntt_note_redo(prep, p, tid);
         } else {
 #if !HX_NTT_NO_SLOW
             slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
@@ -504,9 +524,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 // by the integer butterflies in a launch of their own right behind this one (k_ntt_redo_*), which also takes the whole batch when the
 // tables are not Shoup tables. With the out-of-line fallback CALLED from these kernels -- inside the walk or behind it -- the allocator
 // parks the second sub-transform's results in scratch on the fast path (inverse: 5.1 M against 6.2 M NTT/s).
-__device__ __forceinline__ void ntt_note_redo(const NttPrep& prep, u32 p, int tid) {
-    if (tid == 0) prep.redo[1 + atomicAdd(prep.redo, 1u)] = p;
-}
 template <int LAZY, bool SEMI = false>
 __global__ __launch_bounds__(1024) void k_ntt_fwd_h(u64* __restrict__ x, const u64* __restrict__ roots, const u64* __restrict__ precon,
                                                     u64 q, NttPrep prep, u32 batch, NttHint hint) {
@@ -645,29 +662,31 @@ __global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u
     }
 }
 
-// the integer butterflies for what the half-transform kernels left: the noted polynomials, or the whole batch under tables that are not
-// Shoup tables (one workgroup per CU at most; an empty list costs a dispatch)
-__global__ __launch_bounds__(1024) void k_ntt_redo_fwd(u64* __restrict__ x, const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q,
-                                                       NttPrep prep, u32 batch) {
+// the integer butterflies for what a fast kernel without a fallback of its own left (the half-transform kernels above, k_ntt_inv_p<14, 4, 0>):
+// the noted polynomials, or the whole batch under tables that are not Shoup tables
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_redo_fwd(u64* __restrict__ x, const u64* __restrict__ roots, const u64* __restrict__ precon,
+                                                                     u64 q, NttPrep prep, u32 batch) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const bool all = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const u32 n = all ? batch : __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll 1
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u32 p = all ? i : prep.redo[1 + i];
-        slow_fwd<15, 5>(x + (size_t(p) << 15), lds, roots, precon, q);
+        slow_fwd<LOGN, LOGE>(x + (size_t(p) << LOGN), lds, roots, precon, q);
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(1024) void k_ntt_redo_inv(u64* __restrict__ x, const u64* __restrict__ iroots, const u64* __restrict__ iprecon, u64 q,
-                                                       u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, NttPrep prep, u32 batch) {
+template <int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_redo_inv(u64* __restrict__ x, const u64* __restrict__ iroots, const u64* __restrict__ iprecon,
+                                                                     u64 q, u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, NttPrep prep, u32 batch) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const bool all = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const u32 n = all ? batch : __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll 1
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u32 p = all ? i : prep.redo[1 + i];
-        slow_inv<15, 5>(x + (size_t(p) << 15), lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        slow_inv<LOGN, LOGE>(x + (size_t(p) << LOGN), lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
         __syncthreads();
     }
 }
@@ -721,6 +740,16 @@ static int reserve_tables(hexl_ctx* ctx, u64 n, NttPrep* pr) {
     pr->fused = 0;
     pr->redo = nullptr;
     return 0;
+}
+// the launch behind the fast kernel is nearly always EMPTY: 32 workgroups (an empty dispatch of one 141 KiB workgroup per CU measured 4.7 us,
+// 5 % of a 512-polynomial launch); a batch under tables that are not Shoup tables runs there once, then the host hint sends it to the
+// dedicated integer kernels
+static unsigned redo_grid(unsigned fast_grid) { return fast_grid < 32u ? fast_grid : 32u; }
+static int reserve_redo(hexl_ctx* ctx, size_t batch, NttPrep* pr) {
+    int rc = hx_reserve_device(ctx, &ctx->d_ntt_redo, &ctx->d_ntt_redo_bytes, (batch + 1) * sizeof(u32));
+    pr->redo = (u32*)ctx->d_ntt_redo;
+    pr->fused = 0;
+    return rc;
 }
 // the preparation as a launch of its own, in front of a transform kernel that does not do it itself
 static int launch_prepare(hexl_ctx* ctx, const u64* roots, const u64* precon, u64 q, const NttPrep& pr) {
@@ -993,10 +1022,22 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
             }))
             return rc;
         pr.fused = fused_prepare_enabled() && slots / 8 >= pr.n / G::T ? 1u : 0u;   // see launch_fwd_x
+        if constexpr (ntt_inv_redo<LOGN, LAZY>) {                                // fallback in a launch of its own behind the fast kernel
+            static PerDeviceOnce once_r;
+            if (int rc = once_r.run(ctx->device, [] {
+                    HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_inv<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
+                    return 0;
+                }))
+                return rc;
+            if (int rc = reserve_redo(ctx, batch, &pr)) return rc;               // (the preparation zeroes the counter: no fused preparation here)
+        }
         if (!pr.fused)
             if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
         hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
                            ir, ip, q, a, ap, b, bp, pr, sc, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
+        if constexpr (ntt_inv_redo<LOGN, LAZY>)
+            hipLaunchKernelGGL((k_ntt_redo_inv<LOGN, LOGE>), dim3(redo_grid((unsigned)slots)), dim3(G::T), G::LDS_USED, ctx->stream, x, ir, ip, q, a, ap, b, bp,
+                               pr, (u32)batch);
         return (int)hipGetLastError();
     }
     if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
@@ -1005,16 +1046,6 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     return (int)hipGetLastError();
 }
 
-// the launch behind the fast kernel is nearly always EMPTY: 32 workgroups (an empty dispatch of one 141 KiB workgroup per CU measured 4.7 us,
-// 5 % of a 512-polynomial launch); a batch under tables that are not Shoup tables runs there once, then the host hint sends it to the
-// dedicated integer kernels
-static unsigned redo_grid(unsigned fast_grid) { return fast_grid < 32u ? fast_grid : 32u; }
-static int reserve_redo(hexl_ctx* ctx, size_t batch, NttPrep* pr) {
-    int rc = hx_reserve_device(ctx, &ctx->d_ntt_redo, &ctx->d_ntt_redo_bytes, (batch + 1) * sizeof(u32));
-    pr->redo = (u32*)ctx->d_ntt_redo;
-    pr->fused = 0;
-    return rc;
-}
 template <int LAZY, bool SEMI = false>
 static int launch_fwd_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, const u64* precon, u64 q, NttPrep pr) {
     using G = Geom<14, 4>;
@@ -1022,7 +1053,7 @@ static int launch_fwd_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
     static PerDeviceOnce once;
     if (int rc = once.run(ctx->device, [] {
             HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_h<LAZY, SEMI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INT));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_fwd<15, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INT));
             return 0;
         }))
         return rc;
@@ -1031,7 +1062,7 @@ static int launch_fwd_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
     const unsigned grid = (unsigned)(batch < (size_t)ctx->num_cu ? batch : (size_t)ctx->num_cu);
     hipLaunchKernelGGL((k_ntt_fwd_h<LAZY, SEMI>), dim3(grid), dim3(G::T), LDS, ctx->stream, x, roots, precon, q, pr, (u32)batch,
                        NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
-    hipLaunchKernelGGL(k_ntt_redo_fwd, dim3(redo_grid(grid)), dim3(G::T), LDS_INT, ctx->stream, x, roots, precon, q, pr, (u32)batch);
+    hipLaunchKernelGGL((k_ntt_redo_fwd<15, 5>), dim3(redo_grid(grid)), dim3(G::T), LDS_INT, ctx->stream, x, roots, precon, q, pr, (u32)batch);
     return (int)hipGetLastError();
 }
 template <int LAZY>
@@ -1042,7 +1073,7 @@ static int launch_inv_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     static PerDeviceOnce once;
     if (int rc = once.run(ctx->device, [] {
             HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_inv_h<LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INT));
+            HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_redo_inv<15, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INT));
             return 0;
         }))
         return rc;
@@ -1051,7 +1082,7 @@ static int launch_inv_h(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
     const unsigned grid = (unsigned)(batch < (size_t)ctx->num_cu ? batch : (size_t)ctx->num_cu);
     hipLaunchKernelGGL((k_ntt_inv_h<LAZY>), dim3(grid), dim3(G::T), LDS, ctx->stream, x, ir, ip, q, pr, sc, (u32)batch,
                        NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
-    hipLaunchKernelGGL(k_ntt_redo_inv, dim3(redo_grid(grid)), dim3(G::T), LDS_INT, ctx->stream, x, ir, ip, q, a, ap, b, bp, pr, (u32)batch);
+    hipLaunchKernelGGL((k_ntt_redo_inv<15, 5>), dim3(redo_grid(grid)), dim3(G::T), LDS_INT, ctx->stream, x, ir, ip, q, a, ap, b, bp, pr, (u32)batch);
     return (int)hipGetLastError();
 }
 

@@ -307,16 +307,18 @@ def test_out_of_range_polynomials_inside_a_persistent_batch(hx, ctx, dev, orc, n
         distinct[fwd] = got
 
 
-@pytest.mark.parametrize("n,batch", [(16384, 1024), (4096, 3000)])
-def test_tables_edited_in_place_between_calls(hx, ctx, dev, orc, n, batch):
+@pytest.mark.parametrize("n,batch,strict", [(16384, 1024, False), (4096, 3000, False), (16384, 700, True)],
+                         ids=["16384-1024", "4096-3000", "16384-700-strict_tier_q_2p52_plus_393217"])
+def test_tables_edited_in_place_between_calls(hx, ctx, dev, orc, n, batch, strict):
     """nothing about the caller's tables may be remembered across calls unless it is re-verified: the same table tensors are
     (1) reused over several calls, (2) edited IN PLACE by one word between calls (same pointers; the reference's answer for
     improper tables is the integer butterflies on exactly those words), (3) restored -- every call must match the oracle for
     the tables as they are AT THAT CALL; forward and inverse tables alternate, as in bench.py. (Written for a table cache whose
     kernels re-hash the tables -- tools/experiments/ntt_table_cache.patch, sound but no faster -- and kept as the guard for any
-    future one.)"""
+    future one.) The strict-tier case also covers the inverse kernel whose integer fallback is a launch of its own (ntt.hip ntt_inv_redo,
+    k_ntt_redo_inv: the whole batch goes there while the tables are not Shoup tables)."""
     import torch
-    q = orc.primes(1, 51, n)[0]
+    q = 4503599627763713 if strict else orc.primes(1, 51, n)[0]
     t = orc.HexlTables(n, q)
     base = np.stack([orc.splitmix(n, 70 + b, q) for b in range(3)])
     x = base[np.arange(batch) % 3].copy()
