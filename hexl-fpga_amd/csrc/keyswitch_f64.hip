@@ -45,6 +45,9 @@ __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswit
 
 // ---- small batches: one transform per workgroup, so that even a single keyswitch spreads over L*L + ... CUs ----
 // step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles
+#ifndef KSF_TIER_WIDE
+#define KSF_TIER_WIDE 1   // mixed-tier kernels (LAZY = -1): 1 = four schedules per forward transform at N = 16384, 0 = lazy period 3 / strict only
+#endif
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     const double* tb = a.tables + size_t(i) * 4 * G::N;
     // no final range reduction (LAZY): |u| <= 2.14p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
     // |result| < p); tests/cpp/f64_selftest.cpp replays exactly this chain against 128-bit integers
-    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+    with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {
         using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (batch 32 at N = 16384: -5 %)
         W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
     });
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     // prod is requested right after the cross-wave re-deal and lands during the remaining passes; result is
     // requested first thing in the epilogue and lands during the (prod - w) * msf multiplications
     double pv[G::E];
-    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+    with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {
         using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (N = 16384: +-0)
         if constexpr (G::HALF_ONLY) {                              // N = 32768: no registers to hold prod during the transform
             W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_up(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce((cd + G::idxA(r, 0))[u32(tid)], m);   // c_d mod q_i (intt1_redu.hpp:36-42)
         const double* tb = a.tables + size_t(i) * 4 * G::N;
-        with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {                                // |u| <= 2.14p; keys behind the cross-wave re-deal
+        with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {                                // |u| <= 2.14p; keys behind the cross-wave re-deal
             WgNttF64<LOGN, LOGE, decltype(T)::value>::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, request_keys);
         });
     }
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
     }
     const double* tb = a.tables + size_t(i) * 4 * G::N;
     u64 praw[G::E];
-    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+    with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {
         WgNttF64<LOGN, LOGE, decltype(T)::value>::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {     // |w| <= 2.14p
 #pragma unroll
             for (int r = 0; r < G::E; ++r) praw[r] = (pi + r * G::T)[u32(tid)];
@@ -558,7 +561,14 @@ int hx_launch_keyswitch_f64(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.skip = p->x_skip ? 1u : 0u;
     a.tiermap = 0;
     for (u32 i = 0; i < p->K; ++i) a.tiermap |= (unsigned long long)(p->tier[i] & 15u) << (4 * i);
-    if (p->mixed) {                                               // limbs of different tiers: the schedule is looked up per transform
+    // Limbs of different tiers: the kernels built with LAZY = -1 look the schedule up per transform (with_tier). They are NOT the default
+    // here: this pipeline serves the batches that do not fill the chip, where latency binds, not FP64 issue, and a kernel that carries
+    // two to four copies of its transforms spills (k_ksf_moddown 80 registers, k_ksl_up 116) -- bridge-seal's chain at 2 ... 48 instances runs
+    // 1-12 % FASTER on the plan-wide tier (round 5, tools/seal_chain_rate.py; 4 instances: 44.3 k against 38.9 k keyswitch/s). The slot-major
+    // pipeline (one launch per tier group, +14 %) and the lone-keyswitch kernels keep their per-limb tiers. HEXL_KS_PER_LIMB=2 selects the
+    // per-transform lookup here as well (tests).
+    static const bool lookup = [] { const char* e = getenv("HEXL_KS_PER_LIMB"); return e && atoi(e) == 2; }();
+    if (p->mixed && lookup) {
         switch (p->logn) {
             case 10: return run_chunk_f64<10, 4, -1>(p, a, stage_mask, ev);
             case 11: return run_chunk_f64<11, 5, -1>(p, a, stage_mask, ev);

@@ -435,7 +435,11 @@ int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.skip = p->x_skip ? 1u : 0u;
     a.tiermap = 0;
     for (u32 i = 0; i < p->K; ++i) a.tiermap |= (unsigned long long)(p->tier[i] & 15u) << (4 * i);
-    if (p->mixed) return run_lat<-1>(p, a, (u32)nb);              // limbs of different tiers: looked up per transform (with_tier)
+    // limbs of different tiers: looked up per transform (with_tier) for a LONE keyswitch (bridge-seal's chain: 48.6 against 49.5 us); two to
+    // four instances measured 2-10 % slower that way than on the plan-wide tier (tools/seal_chain_rate.py, round 5) and keep the latter --
+    // HEXL_KS_PER_LIMB=2: the lookup for every batch (tests; keyswitch_f64.hip has the same knob)
+    static const bool lookup = [] { const char* e = getenv("HEXL_KS_PER_LIMB"); return e && atoi(e) == 2; }();
+    if (p->mixed && (nb == 1 || lookup)) return run_lat<-1>(p, a, (u32)nb);
     switch (p->f64_lazy) {
         case 12: return run_lat<12>(p, a, (u32)nb);
         case 6:  return run_lat<6>(p, a, (u32)nb);

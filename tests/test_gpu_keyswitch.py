@@ -506,10 +506,15 @@ def test_lone_keyswitch_latency_path(tier, L, K):
 @pytest.mark.parametrize("n,L,K,nb,env", [(16384, 6, 7, 5, {"HEXL_KS_LAT": "0"}),                       # five kernels, one transform per workgroup
                                           (16384, 3, 4, 160, {"HEXL_KS_PIPE": "1"}),                    # large batch kept off the slot-major pipeline
                                           (16384, 6, 7, 2, {"HEXL_KS_LAT": "1"}),                       # the three-kernel path (k_ksl_*)
+                                          (16384, 6, 7, 2, {}),                                          # two instances in one launch of the quarter-transform kernels
                                           (32768, 3, 4, 6, {}), (4096, 3, 4, 9, {"HEXL_KS_LAT": "0"})])
 def test_bd_major_kernels_with_limbs_of_different_tiers(tier, n, L, K, nb, env):
-    """keyswitch_f64.hip: the (b, d)-major kernels built with LAZY = -1 look the reduction schedule up per transform (with_tier)"""
+    """keyswitch_f64.hip: the (b, d)-major kernels built with LAZY = -1 look the reduction schedule up per transform (with_tier;
+    HEXL_KS_PER_LIMB=2 -- by default this pipeline runs plans of mixed tiers on the plan-wide tier, which measured faster at the batch
+    sizes it serves: the second run)"""
     tenv, moduli = TIERS[tier]
+    if tenv.get("HEXL_KS_PER_LIMB") != "0":
+        _alternative(dict(tenv, **env, HEXL_KS_PER_LIMB="2"), n, L, K, nb, moduli)
     _alternative(dict(tenv, **env), n, L, K, nb, moduli)
 
 
