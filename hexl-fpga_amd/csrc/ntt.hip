@@ -668,8 +668,11 @@ template <int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_redo_fwd(u64* __restrict__ x, const u64* __restrict__ roots, const u64* __restrict__ precon,
                                                                      u64 q, NttPrep prep, u32 batch) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const bool all = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    const u32 n = all ? batch : __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (both words requested before either is looked at: the launch is nearly always empty and its duration is these loads' latency)
+    const u32 bad = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 noted = __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool all = bad != 0;
+    const u32 n = all ? batch : noted;
 #pragma unroll 1
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u32 p = all ? i : prep.redo[1 + i];
@@ -681,8 +684,11 @@ template <int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_redo_inv(u64* __restrict__ x, const u64* __restrict__ iroots, const u64* __restrict__ iprecon,
                                                                      u64 q, u64 inv_n, u64 inv_n_p, u64 inv_n_w, u64 inv_n_w_p, NttPrep prep, u32 batch) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const bool all = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    const u32 n = all ? batch : __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (both words requested before either is looked at: the launch is nearly always empty and its duration is these loads' latency)
+    const u32 bad = __hip_atomic_load(prep.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 noted = __hip_atomic_load(prep.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool all = bad != 0;
+    const u32 n = all ? batch : noted;
 #pragma unroll 1
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u32 p = all ? i : prep.redo[1 + i];
