@@ -11,11 +11,12 @@ def shard_range(total: int, world: int, rank: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def max_over_ranks(seconds: float, device=None) -> float:
-    """wall time of the slowest rank (bench.py contract); identity when not distributed"""
+def max_over_ranks(seconds: float, device=None, force: bool = False) -> float:
+    """wall time of the slowest rank (bench.py contract); identity when not distributed. `force`: run the reduce even in a
+    group of one rank (bench.py's HEXL_BENCH_FORCE_DIST: the RCCL path executed on a one-GPU box)"""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
