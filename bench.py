@@ -405,7 +405,7 @@ def key_stream_split(traffic_per_ks, traffic_per_ks_keys_aliased):
     return {"key_stream_bytes_per_keyswitch": traffic_per_ks - traffic_per_ks_keys_aliased,
             "dram_side_estimate_bytes_per_keyswitch": traffic_per_ks_keys_aliased,
             "dram_side_estimate_note": "L2-miss-side bytes (2 x FETCH_SIZE + WRITE_SIZE) of the same passes with every key row aliased onto row 0 "
-                                       "(HEXL_KSX_ALIAS=1 on libhexl_mi355x_keyalias.so: the shipped kernel objects, one launcher function differs): "
+                                       "(HEXL_KSX_ALIAS=1 on tools/lib_var/libhexl_mi355x_keyalias.so: the shipped kernel objects, one launcher function differs): "
                                        "the key stream (L2 misses served by the Infinity Cache) removed"}
 
 
@@ -442,7 +442,7 @@ def pmc_inrun(L, cus, timeout_s=90):
     """The roofline block's counter inputs measured INSIDE this benchmark run: rocprofv3 PMC passes (one counter group per
     run, --kernel-trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE and WRITE_SIZE in their own passes) of the native
     workload tools/pmc_workload (2 launches of a 256-keyswitch chunk, same library, same kernels), plus two passes of the
-    KEY-ALIAS variant (tools/pmc_workload_keyalias on lib/libhexl_mi355x_keyalias.so: the shipped library's own kernel OBJECTS, only
+    KEY-ALIAS variant (tools/pmc_workload_keyalias on tools/lib_var/libhexl_mi355x_keyalias.so: the shipped library's own kernel OBJECTS, only
     the launcher lets HEXL_KSX_ALIAS=1 point every key row at row 0; the shipped library has no such knob): the difference is the key
     stream's share of the L2-miss-side bytes, which the 256 MiB Infinity Cache serves (the key set is 14.7 MB), so what is left
     estimates the DRAM side. (Rounds 3-4 took the aliased passes from the PROFILING build, whose kernels spill more and move 19.2 MB

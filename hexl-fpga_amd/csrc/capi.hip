@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "hexl_internal.hpp"
 #include "number_theory.hpp"
@@ -27,6 +28,23 @@ int hx_reserve_pinned(hexl_ctx* ctx, void** p, size_t* cur, size_t need, bool co
     return 0;
 }
 
+// NUMA node the library's own host threads (copy pool, unpack lane) ask for: the node of the devices in use when they all hang off one
+// node, else no preference (host_simd.cpp; round 6: +16 % on the host-pointer KeySwitch at worksize 128). -2 = no context yet.
+int hx_numa_node_of_pci(const char* bdf);
+bool hx_pin_this_thread_to_node(int node);
+static std::atomic<int> g_host_node{-2};
+static void note_device_node(int device) {
+    static const bool pin = [] { const char* e = getenv("HEXL_HOST_PIN"); return !(e && atoi(e) == 0); }();
+    if (!pin) { g_host_node.store(-1); return; }
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); bdf[0] = 0; }
+    for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = char(*c - 'A' + 'a');     // sysfs names are lower case
+    const int node = hx_numa_node_of_pci(bdf);
+    int seen = g_host_node.load();
+    while (!g_host_node.compare_exchange_weak(seen, seen == -2 ? node : (seen == node ? node : -1))) {}
+}
+static void pin_own_thread() { (void)hx_pin_this_thread_to_node(g_host_node.load()); }
+
 extern "C" int hexl_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -47,6 +65,7 @@ extern "C" int hexl_ctx_create(int device, hexl_ctx** out) {
              prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
     HX_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    note_device_node(device);
     *out = c;
     return 0;
 }
@@ -454,6 +473,9 @@ extern "C" int hexl_ks_time_stages(hexl_ks_plan* p, uint64_t* d_result, const ui
 #include <condition_variable>
 #include <memory>
 
+// the host's `result += output` per limb (host_simd.cpp)
+void hx_add_mod_u64(uint64_t* r, const uint64_t* o, size_t n, uint64_t q);
+
 static unsigned host_threads() {                                   // (thread-safe static: several device runners call this)
     static const unsigned n = [] {
         const char* e = getenv("HEXL_HOST_THREADS");
@@ -509,6 +531,7 @@ class HostPool {
         }
     }
     void loop() {
+        pin_own_thread();                                             // (the pool is created by the first copy: contexts exist by then)
         for (;;) {
             std::shared_ptr<HostJob> j;
             {
@@ -560,6 +583,7 @@ class AsyncLane {
     }
   private:
     void loop() {
+        pin_own_thread();
         std::unique_lock<std::mutex> g(m_);
         for (;;) {
             cv_.wait(g, [&] { return stop_ || !q_.empty(); });
@@ -616,20 +640,25 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(),
                     fmod(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1e8));
     };
-    // at least four sub-batches once there are four items, so that the stages overlap for small windows too
-    const size_t S = std::min(sh.sub, std::max<size_t>(1, (batch + 3) / 4));
+    // at least four sub-batches once there are four items -- eight from 64 items up -- so that the stages overlap for small windows
+    // too: the window's first upload and last unpack are exposed, and they shrink with the sub-batch (round 6 trace at worksize 128,
+    // profiles/r06_host_trace_worksize128.txt: 1.7 ms of ramp-up with four sub-batches of 32)
+    const size_t S = std::min(sh.sub, std::max<size_t>(1, batch >= 64 ? (batch + 7) / 8 : (batch + 3) / 4));
     const size_t in_slab = (sh.shared + S * sh.in1 + 255) & ~size_t(255);
-    // in-place primitives compute inside the device input slab, but on the HOST side every slab set has its own
-    // download area, so that unpacking sub-batch k can overlap packing sub-batch k+2 into the same set
+    // in-place primitives compute inside the device input slab, but on the HOST side the download areas are separate from the upload
+    // areas and there are FOUR of them (two of everything else): the unpack -- for a keyswitch the host's `result +=`, the slowest
+    // stage of the pipeline -- of sub-batch k then only has to be finished before the download of sub-batch k + 4 is enqueued, not k + 2
+    // (round 6: with two, every other download waited for an unpack and the copy engine idled behind the host)
+    constexpr size_t HOUT = 4;
     const size_t out_slab = (S * (sh.in_place ? sh.in1 : sh.out1) + 255) & ~size_t(255);
-    const size_t hset = in_slab + out_slab, dset = in_slab + (sh.in_place ? 0 : out_slab);
+    const size_t dset = in_slab + (sh.in_place ? 0 : out_slab);
     rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, 2 * dset);
-    if (!rc) rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, 2 * hset);
+    if (!rc) rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, 2 * in_slab + HOUT * out_slab);
     if (rc) return rc;
     const size_t nsub = (batch + S - 1) / S;
-    auto h_in = [&](size_t k) { return (char*)c->h_stage + (k & 1) * hset; };
+    auto h_in = [&](size_t k) { return (char*)c->h_stage + (k & 1) * in_slab; };
     auto d_in = [&](size_t k) { return (char*)c->d_stage + (k & 1) * dset; };
-    auto h_out = [&](size_t k) { return h_in(k) + in_slab; };
+    auto h_out = [&](size_t k) { return (char*)c->h_stage + 2 * in_slab + (k % HOUT) * out_slab; };
     auto d_out = [&](size_t k) { return sh.in_place ? d_in(k) + sh.shared : d_in(k) + in_slab; };
     if (nsub == 1) {
         // one sub-batch: nothing to overlap with -- one stream, one synchronisation, the unpack on the calling thread
@@ -649,9 +678,9 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     }
     // unpack(k) runs on the helper lane beside pack(k+2), strictly in submission order (a keyswitch unpack ACCUMULATES
     // into the caller's result, and the same result may appear in several sub-batches, benchmark/bench_keyswitch.cpp:
-    // 113-131); it must be finished before the download of sub-batch k+2 is enqueued (same host slab)
+    // 113-131); it must be finished before the download of sub-batch k + HOUT is enqueued (same host download area)
     static thread_local AsyncLane lane;
-    size_t ticket[2] = {0, 0}, last_ticket = 0;
+    size_t ticket[HOUT] = {}, last_ticket = 0;
     struct Drain {                                                // the posted jobs reference this frame: never leave before them
         AsyncLane& l; size_t& t;
         ~Drain() { l.wait(t); }
@@ -662,7 +691,7 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
             HX_CHECK(hipEventSynchronize(c->ev_down[k & 1]));
             stamp("download complete", k);
             const char* src = h_out(k);
-            last_ticket = ticket[k & 1] = lane.post([&unpack, &stamp, first, cnt, src, k] { unpack(first, cnt, src); stamp("unpacked", k); });
+            last_ticket = ticket[k % HOUT] = lane.post([&unpack, &stamp, first, cnt, src, k] { unpack(first, cnt, src); stamp("unpacked", k); });
         }
         if (it < nsub) {
             const size_t first = it * S, cnt = std::min(S, batch - first);
@@ -676,7 +705,7 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
             if (rc) break;
             HX_CHECK(hipEventRecord(c->ev_comp[it & 1], c->stream));
             HX_CHECK(hipStreamWaitEvent(c->s_down, c->ev_comp[it & 1], 0));
-            lane.wait(ticket[it & 1]);
+            lane.wait(ticket[it % HOUT]);                         // (the unpack of sub-batch it - HOUT: this download area's last reader)
             HX_CHECK(hipMemcpyAsync(h_out(it), d_out(it), cnt * (sh.in_place ? sh.in1 : sh.out1), hipMemcpyDeviceToHost,
                                     c->s_down));
             HX_CHECK(hipEventRecord(c->ev_down[it & 1], c->s_down));
@@ -875,10 +904,17 @@ static int keyswitch_host_lone(hexl_ks_plan* p, uint64_t* const* h_results, cons
         const u64 q = p->moduli[limb % L];
         const u64* o = out + limb * n;
         u64* r = res + limb * n;
-        for (size_t j = 0; j < n; ++j) { const u64 v = r[j] + o[j]; r[j] = v - (q & (0 - (u64)(v >= q))); }
+        hx_add_mod_u64(r, o, n, q);                                              // host_simd.cpp (AVX-512 / AVX2 / portable)
     };
     // a quarter limb has landed when its word shows this call's epoch (released by the kernel behind the data); a launch that died
     // never publishes: give up after the stream has gone idle without it
+    // (spinning pool workers share the process-wide HostPool with other device runners: after a few thousand polls they yield)
+    auto relax = [](unsigned spins) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0xFFF) == 0xFFF) std::this_thread::yield();
+    };
     std::atomic<bool> lost{false};
     auto wait_limb = [&](size_t x) -> bool {                                    // x = b * 2L + limb
         for (int qd = 0; qd < 4; ++qd) {
@@ -887,7 +923,7 @@ static int keyswitch_host_lone(hexl_ks_plan* p, uint64_t* const* h_results, cons
                 if (lost.load(std::memory_order_relaxed)) return false;
                 if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(c->stream) != hipErrorNotReady &&
                     __atomic_load_n(w, __ATOMIC_ACQUIRE) != epoch) { lost.store(true); return false; }
-                __builtin_ia32_pause();
+                relax(spins);
             }
         }
         return true;
@@ -898,7 +934,7 @@ static int keyswitch_host_lone(hexl_ks_plan* p, uint64_t* const* h_results, cons
                 lost.store(true);
                 return false;
             }
-            __builtin_ia32_pause();
+            relax(spins);
         }
         return true;
     };
@@ -954,7 +990,9 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
     // a lone keyswitch (or the few that still take the quarter-transform path): zero-copy, no staging pipeline. HEXL_HOST_ZERO_COPY=0
     // keeps the staged route (comparisons)
     static const bool zero_copy = [] { const char* e = getenv("HEXL_HOST_ZERO_COPY"); return !(e && atoi(e) == 0); }();
-    if (zero_copy && p->use_f64 && p->have_keys && batch <= 8 && hx_ks_lat_applies(p, batch) && hx_ks_can_overwrite(p, batch))
+    // (one quarter-transform launch must cover the whole call -- its completion words and output gate are per launch: a batch that
+    // HEXL_KS_CHUNK would cut into several chunks takes the staged route)
+    if (zero_copy && p->use_f64 && p->have_keys && batch <= 8 && batch <= hx_ks_chunk(p) && hx_ks_lat_applies(p, batch) && hx_ks_can_overwrite(p, batch))
         return keyswitch_host_lone(p, h_results, h_t_targets, batch);
     // The FP64 kernels flag t_target words that are not below their modulus (the device-side result buffer starts at zero or
     // is written here, so `result` is the host's business). The status covers THIS call: the flag is cleared on the stream
@@ -972,7 +1010,7 @@ extern "C" int hexl_keyswitch_host(hexl_ks_plan* p, uint64_t* const* h_results, 
         const u64 q = p->moduli[limb % L];
         const u64* o = out + limb * n;
         u64* r = res + limb * n;
-        for (size_t j = 0; j < n; ++j) { const u64 v = r[j] + o[j]; r[j] = v - (q & (0 - (u64)(v >= q))); }
+        hx_add_mod_u64(r, o, n, q);                                              // host_simd.cpp (AVX-512 / AVX2 / portable)
     };
     auto add_into = [&](u64* res, const u64* out) {
         for (size_t limb = 0; limb < 2 * L; ++limb) add_limb(res, out, limb);

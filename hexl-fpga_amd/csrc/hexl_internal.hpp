@@ -158,6 +158,7 @@ int hx_launch_keyswitch_f64(hexl_ks_plan*, u64* d_result, const u64* d_t_target,
 int hx_launch_keyswitch_x(hexl_ks_plan*, u64* d_result, const u64* d_t_target, size_t nb, int stage_mask,
                           hipEvent_t* ev);
 bool hx_ks_x_applies(const hexl_ks_plan*, size_t nb);
+size_t hx_ks_chunk(const hexl_ks_plan*);      // instances per scratch chunk (HEXL_KS_CHUNK or the default for the ring dimension)
 // true when a batch of nb runs entirely on kernels that honour hexl_ks_plan::overwrite_result
 bool hx_ks_can_overwrite(const hexl_ks_plan*, size_t nb);
 // the lone-keyswitch latency path (keyswitch_lat.hip): N = 16384, FP64 plans; one instance per call on p->cur / p->cur_scratch

@@ -186,11 +186,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_moddown(KsArgs a) {
 template <class G>
 __device__ __forceinline__ void mac_keys_i(u64 (&acc0)[G::E], u64 (&acc1)[G::E], u64 (&v)[G::E], const u64* __restrict__ k0,
                                            const u64* __restrict__ next, int tid, const KsModulus& md) {
-#ifndef KSI_PF32
-#define KSI_PF32 4
-#define KSI_PF16 2
-#endif
-    constexpr int PF = G::E >= 32 ? KSI_PF32 : KSI_PF16;
+    constexpr int PF = G::E >= 32 ? 4 : 2;                  // key ring depth (deeper rings cost registers: 80.7 k against 92 k keyswitch/s at eight)
     const RowStream<u64> keys(k0, 4 * G::N * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8;
     const ModConst mc = mod_const(md.q);
@@ -429,6 +425,7 @@ static size_t ks_chunk_default(const hexl_ks_plan* p) {
     return p->logn >= 14 ? size_t(256) >> (p->logn - 14) : size_t(256) << (14 - p->logn);
 }
 
+size_t hx_ks_chunk(const hexl_ks_plan* p) { return ks_chunk_default(p); }
 size_t hx_ks_f64_scratch_words(size_t L);
 static size_t scratch_words(const hexl_ks_plan* p) {           // per instance, in units of n 64-bit words
     return p->use_f64 ? hx_ks_f64_scratch_words(p->L) : size_t(3) * p->L + 2;

@@ -45,9 +45,7 @@ __device__ __forceinline__ u32 xcd_item_f(u32 bid, u32 total) {   // see keyswit
 
 // ---- small batches: one transform per workgroup, so that even a single keyswitch spreads over L*L + ... CUs ----
 // step 1: c_d = INTT_{q_d}(t_target[d]) as canonical doubles
-#ifndef KSF_TIER_WIDE
-#define KSF_TIER_WIDE 1   // mixed-tier kernels (LAZY = -1): 1 = four schedules per forward transform at N = 16384, 0 = lazy period 3 / strict only
-#endif
+// mixed-tier kernels (LAZY = -1): four schedules per forward transform at N = 16384 (two -- lazy period 3 / strict -- measured no faster)
 template <int LOGN, int LOGE, int LAZY>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_intt(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
@@ -106,8 +104,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_ntt_up(KsArgsF a) {
     const double* tb = a.tables + size_t(i) * 4 * G::N;
     // no final range reduction (LAZY): |u| <= 2.14p, which mul_mod in k_ksf_mac accepts (|u.key| < 2^102,
     // |result| < p); tests/cpp/f64_selftest.cpp replays exactly this chain against 128-bit integers
-    with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {
-        using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (batch 32 at N = 16384: -5 %)
+    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+        using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (batch 32 at N = 16384: -5 %)
         W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
     });
 #pragma unroll
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_up(KsArgsF a) {
     using G = Geom<LOGN, LOGE>;
     // FPRIO 1222: this workgroup runs L transforms back to back -- the pass in front of the cross-wave barrier at the lower wave
     // priority (ntt_core_f64.hpp hx_fwd_prio): N = 32768, L = 3, batch 2048: 143.5 k -> 163.5 k keyswitch/s (+14 %)
-    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, false, KSF_UP_PRIO>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, false, KSF_UP_PRIO>;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const u32 L = a.L;
     const u32 item = blockIdx.x;                                  // b*L + d
@@ -264,8 +262,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksf_moddown(KsArgsF a) {
     // prod is requested right after the cross-wave re-deal and lands during the remaining passes; result is
     // requested first thing in the epilogue and lands during the (prod - w) * msf multiplications
     double pv[G::E];
-    with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {
-        using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (N = 16384: +-0)
+    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
+        using W = WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, false, (LOGN >= 15 ? KSF_BIG_PRIO : 0)>;   // N = 32768: +7 % (N = 16384: +-0)
         if constexpr (G::HALF_ONLY) {                              // N = 32768: no registers to hold prod during the transform
             W::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m);
 #pragma unroll
@@ -341,7 +339,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_intt(KsArgsF a) {
     for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);   // canonical words as they are
     hxf::report_range(bad, a.range_flag);
     with_tier<LAZY, false>(a.tiermap, d, [&](auto T) {
-        WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, true>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+        WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, true>::template inverse<true>(v, ldsd, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
     });
     double* dst = a.c + size_t(item) * G::N;
 #pragma unroll
@@ -380,7 +378,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_up(KsArgsF a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce((cd + G::idxA(r, 0))[u32(tid)], m);   // c_d mod q_i (intt1_redu.hpp:36-42)
         const double* tb = a.tables + size_t(i) * 4 * G::N;
-        with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {                                // |u| <= 2.14p; keys behind the cross-wave re-deal
+        with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {                                // |u| <= 2.14p; keys behind the cross-wave re-deal
             WgNttF64<LOGN, LOGE, decltype(T)::value>::template forward<true, false>(v, ldsd, tid, tb, tb + G::N, m, request_keys);
         });
     }
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
         for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52(fold_below_q<4>((psp + r * G::T)[u32(tid)], qsp));
         const double* ts = a.tables + size_t(a.K - 1) * 4 * G::N;
         with_tier<LAZY, false>(a.tiermap, a.K - 1, [&](auto T) {
-            WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, 0, true>::template inverse<true>(v, ldsd, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
+            WgNttF64<LOGN, LOGE, decltype(T)::value, 0, 0, true>::template inverse<true>(v, ldsd, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
         });
         // y = s' - floor(q_sp/2), the exact centred remainder (keyswitch_x.hip ksx_special_down; intt2_redu.hpp:25-51), A order
 #pragma unroll
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksl_down(KsArgsF a) {
     }
     const double* tb = a.tables + size_t(i) * 4 * G::N;
     u64 praw[G::E];
-    with_tier<LAZY, KSF_TIER_WIDE && LOGN == 14>(a.tiermap, i, [&](auto T) {
+    with_tier<LAZY, LOGN == 14>(a.tiermap, i, [&](auto T) {
         WgNttF64<LOGN, LOGE, decltype(T)::value>::template forward<false, false>(v, ldsd, tid, tb, tb + G::N, m, [&] {     // |w| <= 2.14p
 #pragma unroll
             for (int r = 0; r < G::E; ++r) praw[r] = (pi + r * G::T)[u32(tid)];

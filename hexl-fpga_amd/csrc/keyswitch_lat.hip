@@ -104,14 +104,14 @@ struct WgSubNtt {
         if constexpr (PASS == 0) {
             // coefficient index >> (LO + K) with LO = 0, K = 4: the quarter on top of the lane's group
             const u32 Gg = (q << (QLOGM - QLOGE)) | u32(GQ::grpB(0, tid));
-            inv_stages_f64<E, 0, QLOGE, 0, QLOGN, false, LAZY, false, 0, true>(v, Gg, iw, iw, m, none);
+            inv_stages_f64<E, 0, QLOGE, 0, QLOGN, false, LAZY, false, true>(v, Gg, iw, iw, m, none);
             inv_pass<1>(v, lds, tid, q, iw, m);
         } else if constexpr (PASS < P) {
             constexpr int LO = PASS * QLOGE;
             redeal_pass<GQ, LO, QLOGE, false, true, (PASS == 1)>(v, lds, tid);
             const u32 Gl = LO + QLOGE >= QLOGM ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             const u32 Gg = (q << (QLOGM - LO - QLOGE)) | Gl;
-            inv_stages_f64<E, 0, QLOGE, LO, QLOGN, false, LAZY, (LO + QLOGE >= QLOGM || LO >= 6), 0, true>(v, Gg, iw, iw, m, none);
+            inv_stages_f64<E, 0, QLOGE, LO, QLOGN, false, LAZY, (LO + QLOGE >= QLOGM || LO >= 6), true>(v, Gg, iw, iw, m, none);
             inv_pass<PASS + 1>(v, lds, tid, q, iw, m);
         }
     }
@@ -130,7 +130,7 @@ __device__ __forceinline__ void b_to_a(double (&v)[GQ::E], double* lds, int tid)
 // transform's last pass does them. Outputs centred (|x| <= p/2 + 2).
 template <int LAZY>
 __device__ __forceinline__ void inverse_finish(double (&a)[4], const double* iw, const Mod m, const hxf::InvScale sc) {
-    inv_stages_f64<4, 0, 2, QLOGM, QLOGN, true, LAZY, true, 0, true>(a, 0u, iw, iw, m, sc);
+    inv_stages_f64<4, 0, 2, QLOGM, QLOGN, true, LAZY, true, true>(a, 0u, iw, iw, m, sc);
 }
 // global forward stages 1 and 2 on the four quarters (inputs centred, |x| <= 0.625p): a[k] becomes quarter k's input to its
 // twelve remaining stages
@@ -360,7 +360,10 @@ __global__ __launch_bounds__(GQ::T) KSQ_ILP void k_ksq_down(KsArgsQ a) {
     const u32 limb = (b * 2 + k) * L + i;
     if (a.gate && limb >= 3) {
         if (tid == 0)
-            while (__hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (limb - 2)) __builtin_amdgcn_s_sleep(8);
+            // (bounded -- ADVICE r05: the gate only orders PCIe stores for latency, so a workgroup that has waited ~2 ms for lower-numbered
+            // ones that are, against all expectation, not resident goes ahead ungated instead of spinning for ever)
+            for (u32 polls = 0; __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (limb - 2) && polls < (1u << 15); ++polls)
+                __builtin_amdgcn_s_sleep(8);
         __syncthreads();
     }
 #pragma unroll
@@ -426,7 +429,8 @@ int hx_launch_keyswitch_lat(hexl_ks_plan* p, u64* d_result, const u64* d_t_targe
     a.tcopy = reinterpret_cast<u64*>(u);                          // (the u region of the (b, d)-major layout is free on this path)
     a.done = p->host_done; a.epoch = p->host_epoch;
     a.started = p->host_done ? p->host_flag + 1 : nullptr;
-    a.gate = (p->host_done && nb * 8 * L <= 256) ? p->d_flag + 2 : nullptr;    // ordered output only while the whole grid is resident
+    // ordered output only while the whole grid of k_ksq_down (256 threads per workgroup: at least one per CU) is resident at once
+    a.gate = (p->host_done && nb * 8 * L <= (size_t)p->ctx->num_cu) ? p->d_flag + 2 : nullptr;
     a.flag_on_host = p->host_flag ? 1u : 0u;
     a.t_target = d_t_target; a.result = d_result;
     a.L = (u32)L; a.K = p->K;

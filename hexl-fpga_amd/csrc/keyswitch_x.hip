@@ -22,11 +22,10 @@
 //    is reloaded inside the multiply-accumulate, and because vector memory returns in order that reload waits for the
 //    whole key prefetch queue -- 37-45 k cycles per multiply-accumulate instead of 10 k. Hence: straight-line phases
 //    instead of one loop with an up/down branch (128 phi nodes on the accumulators cost ~200 spills), the inverse
-//    transforms in their own kernel (two twiddle tables: 92 working registers), no persistent item loop around k_ksx_main
-//    (KX_MAIN_PERSIST), a key ring of three pairs, not six.
-//  * 16 x 1024 beats 32 x 512 (256 VGPRs, two re-deals instead of three): with two waves per SIMD every exposed load
-//    latency is paid in full; HEXL_KSX_LOGE=5 still selects that geometry (its natural-order arrays then meet the
-//    transforms' "B" register order through an LDS re-deal: a lane owns 16 adjacent words there).
+//    transforms in their own kernel (two twiddle tables: 92 working registers), no persistent item loop around k_ksx_main,
+//    a key ring of three pairs, not six.
+//  * 16 x 1024 beats 32 x 512 (256 VGPRs, two re-deals instead of three; 173 k against 209 k keyswitch/s on the round-4 kernels): with
+//    two waves per SIMD every exposed load latency is paid in full. The 32 x 512 variants are gone from the build (round 6).
 //  * The NEXT round's input is requested inside the multiply-accumulate, into the registers the products free.
 //  * Per-lane twiddles are requested by hand ahead of their butterflies (KX_PRE, KX_IPRE): with 96 data registers the
 //    compiler otherwise puts each load in front of its first use and waits for it on the spot.
@@ -53,53 +52,14 @@
 
 using namespace hx;
 
-#ifndef KX_TF
-#define KX_TF 0      // twiddle ring of the transforms (ntt_core_f64.hpp); 0 = off
-#endif
-#ifndef KX_SLOT_MAJOR
-#define KX_SLOT_MAJOR 0
-#endif
-#ifndef KX_MAIN_PERSIST
-#define KX_MAIN_PERSIST 0   // k_ksx_main as a persistent item loop per CU
-#endif
-#ifndef KX_FIRST_DIRECT
-#define KX_FIRST_DIRECT 1   // first multiply-accumulate of k_ksx_main with its keys requested straight into the accumulators
-#endif
-#ifndef KX_DL_SELECT
-#define KX_DL_SELECT 0   // DL: 1 = one loop over all d != i with a run-time choice of the next-input addressing in its multiply-accumulate
-#endif
-#ifndef KX_DL_PF
-#define KX_DL_PF 2       // key ring depth of the two peeled multiply-accumulates of k_ksx_main<..., DL>
-#endif
-#ifndef KX_DIAG_LATE
-#define KX_DIAG_LATE 0   // 1: k_ksx_main<..., DL> (the d == i term as the LAST multiply-accumulate of the mod-up instead of a start-up phase of
-                         // its own) is built and used for N = 16384, L >= 2 (HEXL_KSX_DIAG=0 switches back at run time). Bit-exact; measured
-                         // 203.5 k against 214.6 k keyswitch/s: the two peeled multiply-accumulates spill accumulators (tools/experiments)
-#endif
+// Tuning constants that were swept on the MI355X and may want re-sweeping on another ROCm (tools/build_variant.sh <name> -D...); every
+// other knob of rounds 2-5 is gone from the source: its experiment is in tools/experiments/ (README.md + r06_pruned_knobs_*.patch).
 #ifndef KX_PRE
 #define KX_PRE 11     // forward transforms: twiddles of the per-lane passes requested early (ntt_core_f64.hpp WgNttF64 PRE): units = groups of
                       // the last pass ahead of its re-deal, tens = early stages of the per-lane full pass up front
 #endif
 #ifndef KX_IPRE
 #define KX_IPRE 1     // k_ksx_intt: the per-lane twiddle pairs of a pass of the inverse transform requested before its butterflies
-#endif
-#ifndef KX_NEXT_AUX
-#define KX_NEXT_AUX 0   // cache policy of the next-input loads inside the multiply-accumulate (2 = non-temporal)
-#endif
-#ifndef KX_PRIO_MASK
-#define KX_PRIO_MASK 0  // k_ksx_main: waves whose number has a bit of this mask set run at s_setprio 1 (experiment)
-#endif
-#ifndef KX_MAC_PRIO
-#define KX_MAC_PRIO 0   // wave priority + 1 of the multiply-accumulate phase (0 = inherit the transform's last pass; HX_FWD_PRIO)
-#endif
-#ifndef KX_EPI_PRIO
-#define KX_EPI_PRIO 0   // ... of the mod-down epilogue (result read-modify-write)
-#endif
-#ifndef KX_MACEND_PRIO
-#define KX_MACEND_PRIO 0   // ... from the end of a multiply-accumulate (the wait for the next round's input)
-#endif
-#ifndef KX_KEY_AUX
-#define KX_KEY_AUX 0    // ... of the key loads
 #endif
 
 // 16 coefficients per thread: the kernels are written for 128 VGPRs = four waves per SIMD, which a 1024-thread workgroup
@@ -110,7 +70,7 @@ using namespace hx;
 // HEXL_KSX_ALIAS=<bit mask> makes every workgroup read one instance's / limb's rows of a stream, which takes that stream out
 // of the L2-miss-side counters and of the fabric's power draw (profiles/r04_bytes.json): 1 = key rows (every row reads row 0),
 // 2 = c and s' reads (instance 0), 4 = t_target reads (instance 0), 8 = result read-modify-write (instance 0), 16 = twiddle
-// tables (limb 0). HEXL_KSX_KEY_ALIAS=1 is the old name of bit 1.
+// tables (limb 0).
 #ifdef HEXL_PROFILING_AIDS
 #define KX_ALIASED(bit, x) ((a.alias & (bit)) ? 0u : (x))
 #else
@@ -236,47 +196,31 @@ constexpr int KX_PF = KX_PF_DEPTH;
 // The two streams of a multiply-accumulate (key rows, next input rows) are read with BUFFER loads (RowStream, ntt_core.hpp).
 // acc_k += v . key_k; k0 points at key[d][slot][0], key[..][1] follows it (n words further); `next` = the next round's
 // input, A order (never null)
-#ifndef KX_SEMI
-#define KX_SEMI 0   // 1: strict kernels with the semi-strict forward transforms (f64_arith.hpp ct_bfly_semi: 11 instead of 14 FP64 instructions per
-                    // butterfly, reads the w/p table, no PRE requests). Bit-exact; measured 159 k against 181 k keyswitch/s at the largest 52-bit primes:
-                    // twice the per-lane twiddle loads and no early requests cost more than the instructions save (19 spilled VGPRs)
-#endif
-#define KX_SEMI_ON(LAZY) ((LAZY) == 0 && KX_SEMI != 0)
+// strict kernels (moduli above the lazy bound): the semi-strict schedule in the wave-uniform passes of their forward transforms
+// (ntt_core_f64.hpp SEMIU; round 5: +1.6 %). The all-passes variant (round 4) lost 12 % to its per-lane w/p loads and is gone.
 #ifndef KX_SEMI_UNI
-#define KX_SEMI_UNI 1   // strict kernels: the semi-strict schedule in the wave-uniform passes only (ntt_core_f64.hpp SEMIU; round 5)
+#define KX_SEMI_UNI 1
 #endif
-#define KX_SEMIU_ON(LAZY) ((LAZY) == 0 && KX_SEMI == 0 && KX_SEMI_UNI != 0)
-#ifndef KX_STRICT_FOLD
-#define KX_STRICT_FOLD 1   // strict kernels (moduli above the lazy bound, up to 2^52): folded multiply-accumulate as well
-#endif
-#ifndef KX_FOLD
-#define KX_FOLD 1     // lazy kernels: folded multiply-accumulate (f64_arith.hpp mac_fold), accumulators <= 1.6p between rounds
-#endif
-// NEXTB: the next input is read at the B-order positions of a natural-order array (the raw t_i words of the d == i term,
-// k_ksx_main<..., DL>) instead of the usual A-order rows.
+#define KX_SEMIU_ON(LAZY) ((LAZY) == 0 && KX_SEMI_UNI != 0)
+// FOLD: the folded multiply-accumulate (f64_arith.hpp mac_fold; lazy tiers: accumulators <= 1.6p between rounds, strict tier <= 0.9p)
 // CSW: words between the two key components of a row (0: G::N; the N = 32768 kernels work on HALF rows of rows that are 2 G::N long)
-template <class G, bool FOLD = false, int NEXTB = 0, int PF = KX_PF, int CSW = 0>
+template <class G, bool FOLD = false, int CSW = 0>
 __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G::E], double (&v)[G::E],
                                          const double* __restrict__ k0, const double* __restrict__ next, int tid,
-                                         const Mod m, bool next_at_B = false) {
-#if KX_MAC_PRIO
-    __builtin_amdgcn_s_setprio(KX_MAC_PRIO - 1);
-#endif
+                                         const Mod m) {
+    constexpr int PF = KX_PF;
     constexpr int CS = CSW ? CSW : G::N;
     const RowStream<double> keys(k0, 2 * CS * 8), nxt(next, G::N * 8);
     const u32 toff = u32(tid) * 8;
-    const bool nb = NEXTB == 1 || (NEXTB == 2 && next_at_B);        // (2: wave-uniform, chosen per call: sixteen scalar selects)
-    const u32 ntoff = nb ? u32(G::idxB(0, tid)) * 8 : toff;
-    auto next_row = [&](int r) -> u32 { return nb ? u32(G::idxB(r, 0)) * 8 : u32(G::idxA(r, 0)) * 8; };
     double ka[PF], kb[PF];
 #pragma unroll
-    for (int r = 0; r < PF; ++r) { ka[r] = keys.template at<KX_KEY_AUX>(toff, r * G::T * 8); kb[r] = keys.template at<KX_KEY_AUX>(toff, (CS + r * G::T) * 8); }
+    for (int r = 0; r < PF; ++r) { ka[r] = keys.at(toff, r * G::T * 8); kb[r] = keys.at(toff, (CS + r * G::T) * 8); }
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
         const double a = ka[r % PF], b = kb[r % PF];
-        if (r + PF < G::E) { ka[r % PF] = keys.template at<KX_KEY_AUX>(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.template at<KX_KEY_AUX>(toff, (CS + (r + PF) * G::T) * 8); }
+        if (r + PF < G::E) { ka[r % PF] = keys.at(toff, (r + PF) * G::T * 8); kb[r % PF] = keys.at(toff, (CS + (r + PF) * G::T) * 8); }
         const double x = v[r];
-        v[r] = nxt.template at<KX_NEXT_AUX>(ntoff, next_row(r));
+        v[r] = nxt.at(toff, G::idxA(r, 0) * 8);
         if constexpr (FOLD) {
             acc0[r] = hxf::mac_fold(acc0[r], x, a, m);
             acc1[r] = hxf::mac_fold(acc1[r], x, b, m);
@@ -286,9 +230,6 @@ __device__ __forceinline__ void mac_keys(double (&acc0)[G::E], double (&acc1)[G:
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#if KX_MACEND_PRIO
-    __builtin_amdgcn_s_setprio(KX_MACEND_PRIO - 1);
-#endif
 }
 
 // The FIRST multiply-accumulate of a workgroup (the d == i term): the accumulators are not live yet, so all 2 E key words
@@ -378,7 +319,7 @@ __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __re
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>;         // inverse without the w/p table
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, true>;            // inverse without the w/p table
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.nsel);
     if (wk.pos >= wk.end) return;
@@ -443,7 +384,7 @@ template <int LOGN, int LOGE, int LAZY, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, KX_SEMI_ON(LAZY), 0, KX_SEMIU_ON(LAZY)>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY)>;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;
@@ -465,7 +406,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     }
     // (Walking the limbs in a different order per instance -- the sum is exact, its order free -- does not shorten this
     // kernel's multiply-accumulate, 12-13 k cycles against 5 k in k_ksx_main: its workgroups start together and stay in
-    // step, so all 16 waves of a CU are in that phase at once and nobody has transform work to cover the key latency.)
+    // step, so all 16 waves of a CU are in that phase at once and nobody has transform work to cover the key latency.
+    // Round 6: neither does a start skew of every other workgroup by 8 k / 16 k cycles, nor a key ring of 4 or 6 pairs in
+    // this kernel only -- 217.6-218.0 k keyswitch/s shipped against 217.0-217.8 k for all four, same box:
+    // tools/experiments/r06_special_dephase.patch.)
 #pragma unroll 1
     for (u32 it = 0; it < L; ++it) {
         int tid = threadIdx.x;                                    // laundered per round (see k_ksf_up)
@@ -483,12 +427,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
         const u32 nd = it + 1 < L ? it + 1 : it;                  // (the last limb is requested twice: harmless)
         W::template forward<false, false>(v, ldsx, tid, ts, ts + G::N, msp.m);
         KX_STAMP(4 * it + 2);
-        mac_keys<G, (KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD))>(acc0, acc1, v, k0, a.c + (size_t(KX_ALIASED(2, b)) * L + nd) * G::N, tid, msp.m);
+        mac_keys<G, true>(acc0, acc1, v, k0, a.c + (size_t(KX_ALIASED(2, b)) * L + nd) * G::N, tid, msp.m);
     }
-    if constexpr (KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD)) {
+    // (the folded multiply-accumulate leaves |acc| <= 1.7p: one reduction in front of the inverse transforms)
 #pragma unroll
-        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
-    }
+    for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -517,17 +460,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
 // multiple of q_i. SKIP: |y_k| <= 0.5 rho q_i goes into the transform as it is (standard schedule: 0.625 -> 3.77 after three
 // stages at rho = 1.25). The accumulators arrive un-reduced from mac_fold in the lazy kernels (|acc| <= 1.7p):
 // |acc - w| <= 1.7p + 2.14p = 3.84p < 2^53 = 3.97p, and mul_shoup of that is exact (|h| < 2^103, |h - k p| <= 1.5p).
-// PREF (KX_RMW_PREF builds, direct B-order read-modify-write only): the first PREF old result words are requested between the
-// transform's last re-deal and its partial pass (`before_last`), behind that pass's twiddles -- vector memory returns in order,
-// so nothing the pass waits for queues behind them -- instead of at the top of the epilogue, where all 16 waves of the workgroup
-// wait out an HBM latency together (~3 k cycles, twice per round). KX_RMW_PREF bits: 1 = k = 0 requests 8 words early (acc_1 is
-// still live), 2 = k = 1 requests all 16, 4 = k = 1 requests 8. Measured (batch 8192, same box): 3 -> 204.1 k against 210.0 k
-// keyswitch/s for 0: the registers cost more than the latency.
-#ifndef KX_RMW_PREF
-#define KX_RMW_PREF 0
-#endif
 // PRED (the N = 32768 kernels): v arrives ready for the sub-transform (already reduced / combined across the halves); `top` = which half
-template <class G, class W, int FUSED_K = -1, bool SKIP = false, int PREF = 0, bool PRED = false>
+template <class G, class W, int FUSED_K = -1, bool SKIP = false, bool PRED = false>
 __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (&acc)[G::E], u64* __restrict__ res,
                                                double* lds, int tid, const double* tb, const KsModF64& md, hxf::RangeMask& bad,
                                                const u64* a0 = nullptr, const u64* a1 = nullptr, const u64* b0 = nullptr,
@@ -537,39 +471,10 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
     }
-    constexpr int NPF = (FUSED_K < 0 && G::KL <= 2) ? PREF : 0;
-    u64 early[NPF > 0 ? NPF : 1];
-    if constexpr (NPF > 0) {
-        const u32 tBe = u32(G::idxB(0, tid));
-        auto request = [&] {
-#pragma unroll
-            for (int r = 0; r < NPF; ++r) early[r] = (res + G::idxB(r, 0))[tBe];
-        };
-        W::template forward<false, false>(v, lds, tid, tb, tb + G::N, m, typename W::NoHook(), request);
-    } else {
-        // (the w/p table -- read by the strict kernels' semi-strict passes only -- lies one FULL transform's worth of words behind w)
-        W::template forward<false, false>(v, lds, tid, tb, tb + (PRED ? 2 : 1) * G::N, m, typename W::NoHook(), typename W::NoHook(), top);   // |w| <= 2.14p
-    }
-#if KX_EPI_PRIO
-    __builtin_amdgcn_s_setprio(KX_EPI_PRIO - 1);
-#endif
+    // (the w/p table -- read by the strict kernels' semi-strict passes only -- lies one FULL transform's worth of words behind w)
+    W::template forward<false, false>(v, lds, tid, tb, tb + (PRED ? 2 : 1) * G::N, m, typename W::NoHook(), typename W::NoHook(), top);   // |w| <= 2.14p
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = hxf::mul_shoup(acc[r] - v[r], md.msf, md.msf_p, m);   // ms.hpp:70-82
-    if constexpr (NPF > 0) {
-        const u32 tB = u32(G::idxB(0, tid));
-        const u64 qi = (u64)m.p;
-        u64 late[G::E - NPF > 0 ? G::E - NPF : 1];
-#pragma unroll
-        for (int r = NPF; r < G::E; ++r) late[r - NPF] = (res + G::idxB(r, 0))[tB];
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) {
-            const u64 o = r < NPF ? early[r < NPF ? r : 0] : late[r >= NPF ? r - NPF : 0];
-            const double rr = hxf::reduce(hxf::to_f64_lt52_checked(o, qi, bad) + v[r], m);       // fpga.cpp:453-457
-            (res + G::idxB(r, 0))[tB] = hxf::from_f64(hxf::lift(rr, m));
-            if (r == NPF - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        return;
-    }
     if constexpr (FUSED_K >= 0 && G::KL <= 2) {
         const u32 tB = u32(G::idxB(0, tid));
         auto ld = [&](const u64* p, int r) { return hxf::reduce(hxf::to_f64((p + G::idxB(r, 0))[tB]), m); };
@@ -635,51 +540,29 @@ __device__ __forceinline__ void ksx_down_round(double (&v)[G::E], const double (
     for (int r = 0; r < G::E; ++r) (res + G::idxA(r, 0))[u32(tid)] = hxf::from_f64(atA[G::pad(G::idxA(r, 0))]);
 }
 
-template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false, bool DL = false>
+template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    // (strict kernels: the semi-strict forward schedule, f64_arith.hpp ct_bfly_semi -- plain twiddle loads, no PRE requests)
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY), 0, KX_SEMIU_ON(LAZY)>;               // mod-down transforms: centred input
-    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_TF, KX_SEMI_ON(LAZY) ? 0 : KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, KX_SEMI_ON(LAZY), 0, KX_SEMIU_ON(LAZY)>;   // mod-up transforms (SKIP: canonical c_d as it is)
-    constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
-    // the strict kernels (moduli up to 2^52) fold their multiply-accumulate too (round 4; f64_arith.hpp mac_fold "strict tier": transform
-    // output |x| <= p/2 + 2, accumulators <= 0.9p between terms) and reduce the accumulators once in front of the mod-down, whose
-    // epilogue needs them centred at this modulus size; the d == i term keeps its reduced form there
-    constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, 0, false, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY)>;               // mod-down transforms: centred input
+    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY)>;   // mod-up transforms (SKIP: canonical c_d as it is)
+    // lazy kernels: the d == i term and the accumulators go un-reduced into the folded multiply-accumulate (f64_arith.hpp mac_fold,
+    // |acc| <= 1.6p between rounds). The strict kernels (moduli up to 2^52) fold theirs too (transform output |x| <= p/2 + 2,
+    // accumulators <= 0.9p between terms) and reduce the accumulators once in front of the mod-down, whose epilogue needs them centred
+    // at this modulus size; the d == i term keeps its reduced form there
+    constexpr bool LAZYFOLD = LAZY != 0;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
-#if KX_PRIO_MASK
-    // experiment: static priority for half of the waves of every SIMD (a workgroup's waves go to the SIMDs cyclically, so waves
-    // w, w + 4, w + 8, w + 12 share one): the favoured pair runs ahead and reaches its LDS re-deals while the other pair still has
-    // butterflies to issue, instead of all four stalling in the same phase
-    if ((threadIdx.x >> 6) & KX_PRIO_MASK) __builtin_amdgcn_s_setprio(1);
-#endif
     const u32 L = a.L;
-    // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 7 % slower -- what the compiler
-    // hoists out of the item loop costs more registers (34 spilled against 10) than the dispatch gaps cost time
-#if KX_MAIN_PERSIST
-    const XcdWalk wk = xcd_walk(a.nb * a.nsel);
-#pragma unroll 1
-    for (u32 item_v = wk.pos; item_v < wk.end; item_v += wk.step)
-#else
-    const u32 item_v = xcd_item_x(blockIdx.x, gridDim.x);
-#endif
+    // one item per workgroup: as a persistent loop (xcd_walk) this kernel measured 2.6-10 % slower in rounds 2-4 (what the compiler hoists
+    // out of the item loop costs more registers than the dispatch gaps cost time; tools/experiments/persistent_main_out_of_line.patch)
     {
-    const u32 item = __builtin_amdgcn_readfirstlane(item_v);
-#if KX_MAIN_PERSIST && HX_FWD_PRIO
-    __builtin_amdgcn_s_setprio(HX_FWD_PRIO / 1000 - 1);          // the d == i phase of the next item: as low as a first pass
-#endif
+    const u32 item = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));
 #ifdef KX_TIMELINE
     const u32 kx_slot = item;
 #endif
-#if KX_SLOT_MAJOR
-    // SLOT-major, XCD-contiguous: an XCD works on one or two limbs at a time, whose keys (2 L n words per limb) then
-    // stay in its L2; c_d and s' of one instance are fetched by up to L XCDs (the Infinity Cache absorbs that)
-    const u32 i = sel_limb(a, item / a.nb), b = item % a.nb;
-#else
-    // instance-major, XCD-contiguous: the workgroups (one per limb of this launch) that read the same c_d and s' run side by side on one XCD
+    // instance-major, XCD-contiguous: the workgroups (one per limb of this launch) that read the same c_d and s' run side by side on one
+    // XCD (slot-major -- an XCD's keys L2-resident, c from the Infinity Cache -- measured slower: 234 against 215 us per generation)
     const u32 b = item / a.nsel, i = sel_limb(a, item - b * a.nsel);
-#endif
     // (through the constant address space: inside an item loop that also stores to global memory a plain read of these
     // wave-uniform constants becomes a VECTOR load, and p, 1/p, msf ... then occupy vector registers the accumulators need)
     const KsModF64 md = load_mod_const(a.mods + i);
@@ -690,116 +573,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
     const u32 first = i == 0 ? 1u : 0u;
     double acc0[G::E], acc1[G::E];
     double v[G::E];                                               // between rounds: the next round's input, A order
-    // DL ("diagonal late", L >= 2 only; the launcher picks it): the d == i term as the LAST multiply-accumulate of the mod-up instead of
-    // a phase of its own at the start. A workgroup that starts with that term waits for 512 KiB (t_i, its two key rows, the first
-    // c_d) with nothing else to do -- 17 k cycles for 3.6 k of issue (tools/ksx_timeline); here it starts on the 128 KiB of the first
-    // c_d, the raw t_i words arrive as the "next input" of the last round's multiply-accumulate (at their B positions: the product
-    // is element-wise) and the term goes through the key ring like every other, beside the other waves' transforms.
-    if constexpr (DL) {
-        static_assert(!FUSED && G::KL <= 2, "direct B-order loads of t_i");
-        const u64* ti = a.t_target + (size_t(bt) * L + i) * G::N;
-        {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            KX_STAMP(60);
-            const RowStream<double> in(round_src(first), G::N * 8);
-            const u32 toff = u32(tid) * 8;
-#pragma unroll
-            for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; v[r] = in.at(toff, G::idxA(r, 0) * 8); }
-            KX_STAMP(61);
-        }
-        const u32 last = i == L - 1 ? L - 2 : L - 1;                  // the last d != i
-        // rounds d != i except the last: acc += NTT(c_d mod q_i) . key[d][i]
-#if KX_DL_SELECT
-        // (one loop over ALL d != i; the last round's multiply-accumulate brings in the raw t_i words in A order like any other input --
-        // only the pointer differs -- and one LDS re-deal takes them to the B positions the accumulators are in)
-#pragma unroll 1
-        for (u32 it = first; it < L;) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            u32 toff = KX_ALIASED(16, i) * 4 * G::N;
-            asm volatile("" : "+s"(toff));
-            const double* tb = a.tables + toff;
-            KX_STAMP(4 * it + 0);
-            if constexpr (!SKIP) {
-#pragma unroll
-                for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
-            }
-            KX_STAMP(4 * it + 1);
-            u32 nit = it + 1;
-            if (nit == i) ++nit;
-            const double* k0 = key_row<G>(a, it, i);
-            WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);
-            KX_STAMP(4 * it + 2);
-            mac_keys<G, FOLD>(acc0, acc1, v, k0, nit < L ? round_src(nit) : (const double*)ti, tid, m);
-            it = nit;
-        }
-        {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            redeal_x<G, false, true>(v, ldsx, tid, [](int r, int t) { return G::idxA(r, t); }, [](int r, int t) { return G::idxB(r, t); });
-        }
-#else
-#pragma unroll 1
-        for (u32 it = first; it != last;) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            u32 toff = KX_ALIASED(16, i) * 4 * G::N;
-            asm volatile("" : "+s"(toff));
-            const double* tb = a.tables + toff;
-            KX_STAMP(4 * it + 0);
-            if constexpr (!SKIP) {
-#pragma unroll
-                for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);             // intt1_redu.hpp:36-42
-            }
-            KX_STAMP(4 * it + 1);
-            u32 nit = it + 1;
-            if (nit == i) ++nit;
-            const double* k0 = key_row<G>(a, it, i);
-            WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);         // |u| <= 2.14p (SKIP: 3.45p)
-            KX_STAMP(4 * it + 2);
-            mac_keys<G, LAZYFOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);
-            it = nit;
-        }
-        {   // the last d != i: its multiply-accumulate brings in the raw t_i words
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            u32 toff = KX_ALIASED(16, i) * 4 * G::N;
-            asm volatile("" : "+s"(toff));
-            const double* tb = a.tables + toff;
-            KX_STAMP(4 * last + 0);
-            if constexpr (!SKIP) {
-#pragma unroll
-                for (int r = 0; r < G::E; ++r) v[r] = hxf::reduce(v[r], m);
-            }
-            KX_STAMP(4 * last + 1);
-            WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);
-            KX_STAMP(4 * last + 2);
-            mac_keys<G, LAZYFOLD, 1, KX_DL_PF>(acc0, acc1, v, key_row<G>(a, last, i), (const double*)ti, tid, m);
-        }
-#endif
-        {   // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            KX_STAMP(4 * i + 0);
-#pragma unroll
-            for (int r = 0; r < G::E; ++r) {
-                u64 bits;
-                __builtin_memcpy(&bits, &v[r], 8);
-                if constexpr (LAZYFOLD) v[r] = hxf::to_f64_lt52(bits);              // t_i < q_i as it comes: mac_fold takes |x| <= 3.45p
-                else v[r] = hxf::reduce(hxf::to_f64_lt52(bits), m);                  // (k_ksx_intt has range-checked these very words)
-            }
-            KX_STAMP(4 * i + 2);
-            mac_keys<G, LAZYFOLD, 0, KX_DL_PF>(acc0, acc1, v, key_row<G>(a, i, i), round_src(L), tid, m);   // s'_0 follows
-        }
-    } else {
     {
         // d == i: NTT_{q_i}(INTT_{q_i}(t_i) mod q_i) = t_i (the reference recomputes it; same value for in-range data)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const double* k0 = key_row<G>(a, i, i);
         KX_STAMP(60);
-        if constexpr (!FUSED && G::KL <= 2 && KX_FIRST_DIRECT) {
+        if constexpr (!FUSED && G::KL <= 2) {
             KX_STAMP(61);
             mac_keys_first<G, LAZYFOLD>(acc0, acc1, v, a.t_target + (size_t(bt) * L + i) * G::N, k0, round_src(first), tid, m);
         } else {
@@ -835,12 +615,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* k0 = key_row<G>(a, it, i);
         WU::template forward<false, false>(v, ldsx, tid, tb, tb + G::N, m);         // |u| <= 2.14p (SKIP: 3.45p)
         KX_STAMP(4 * it + 2);
-        mac_keys<G, FOLD>(acc0, acc1, v, k0, round_src(nit), tid, m);               // nit <= L: s'_0 follows the last c_d
+        mac_keys<G, true>(acc0, acc1, v, k0, round_src(nit), tid, m);               // nit <= L: s'_0 follows the last c_d
         it = nit;
     }
-    }
     // (lazy kernels: the accumulators stay as mac_fold leaves them, |acc| <= 1.7p -- ksx_down_round)
-    if constexpr (FOLD && LAZY == 0) {
+    if constexpr (LAZY == 0) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
     }
@@ -855,7 +634,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         KX_STAMP(4 * L + 0);
         const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W, -1, SKIP, ((KX_RMW_PREF & 1) ? G::E / 2 : 0)>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
+        else ksx_down_round<G, W, -1, SKIP>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad);
         const double* nxt = a.s + (size_t(bc) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -869,7 +648,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
         const double* tb = a.tables + toff;
         const size_t o0 = ((size_t(br) * 2 + 0) * L + i) * G::N, o1 = ((size_t(br) * 2 + 1) * L + i) * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1);
-        else ksx_down_round<G, W, -1, SKIP, ((KX_RMW_PREF & 2) ? G::E : (KX_RMW_PREF & 4) ? G::E / 2 : 0)>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
+        else ksx_down_round<G, W, -1, SKIP>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad);
         KX_STAMP(4 * L + 8);
         hxf::report_range(bad, a.range_flag);
     }
@@ -893,9 +672,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
 // The NTT-domain index space splits into contiguous blocks (sub-transform h produces / consumes block h), so t_target, the keys and
 // result need no exchange at all; only the coefficient-domain arrays (c_d, s') are read in full by both halves: + 1 load, a reduction and
 // 7 FP64 operations per coefficient and round. Same arithmetic as the monolithic transforms of the (b, d)-major kernels: bit-identical.
-#ifndef KSH_HB
-#define KSH_HB 8      // words of the other half requested at a time in ksh_combine
-#endif
+constexpr int KSH_HB = 8;      // words of the other half requested at a time in ksh_combine
 template <class G, int LAZY, bool SKIP, int SHIFT>
 __device__ __forceinline__ void ksh_combine(double (&v)[G::E], const double* __restrict__ hi_row, int tid, const double* w, const Mod m, u32 h) {
     // forward global stage 1 of the 2^15-point transform (one twiddle: index 1), this workgroup keeps output half h
@@ -925,7 +702,7 @@ __device__ __forceinline__ void ksh_combine(double (&v)[G::E], const double* __r
 template <int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1024, 4) void k_ksh_intt(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, 0, 0, 0, true, HX_FWD_PRIO, false, 1>;
+    using W = WgNttF64<14, 4, LAZY, 0, 0, true, HX_FWD_PRIO, 1>;
     constexpr u32 NF = 2 * G::N;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.nsel * 2);
@@ -973,7 +750,7 @@ __global__ __launch_bounds__(256) void k_ksh_finish(KsArgsX a, u32 rows) {
     const double* tb = a.tables + size_t(limb) * 4 * NF;
     const double* sub = (WHICH == 0 ? a.csub : a.ssub) + size_t(row) * NF;
     double x[2] = {sub[j], sub[H + j]};
-    inv_stages_f64<2, 0, 1, 14, 15, true, 3, true, 0, true>(x, 0u, tb + 2 * NF, tb + 3 * NF, md.m, md.sc);
+    inv_stages_f64<2, 0, 1, 14, 15, true, 3, true, true>(x, 0u, tb + 2 * NF, tb + 3 * NF, md.m, md.sc);
     double* dst = (WHICH == 0 ? a.c : a.s) + size_t(row) * NF;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -985,9 +762,8 @@ __global__ __launch_bounds__(256) void k_ksh_finish(KsArgsX a, u32 rows) {
 template <int LAZY, bool SKIP>
 __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;
+    using W = WgNttF64<14, 4, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY)>;
     constexpr u32 NF = 2 * G::N;
-    constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L, isp = a.K - 1;
     const KsModF64 msp = a.mods[isp];
@@ -1014,12 +790,10 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
             const double* k0 = key_row<G>(a, it, L) + h * G::N;
             const u32 nd = it + 1 < L ? it + 1 : it;
             W::template forward<false, false>(v, ldsx, tid, ts, ts + NF, msp.m, typename W::NoHook(), typename W::NoHook(), h);
-            mac_keys<G, FOLD, 0, KX_PF, int(NF)>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * NF, tid, msp.m);
+            mac_keys<G, true, int(NF)>(acc0, acc1, v, k0, a.c + (size_t(b) * L + nd) * NF, tid, msp.m);
         }
-        if constexpr (FOLD) {
 #pragma unroll
-            for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
-        }
+        for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], msp.m); acc1[r] = hxf::reduce(acc1[r], msp.m); }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             int tid = threadIdx.x;
@@ -1039,11 +813,10 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
 template <int LAZY, bool SKIP, bool FUSED = false>
 __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, 0, false, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;                 // mod-down transforms: centred input
-    using WU = WgNttF64<14, 4, LAZY, KX_TF, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, false, 1, KX_SEMIU_ON(LAZY)>;     // mod-up transforms
+    using W = WgNttF64<14, 4, LAZY, KX_PRE, 0, false, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY)>;                 // mod-down transforms: centred input
+    using WU = WgNttF64<14, 4, LAZY, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY)>;     // mod-up transforms
     constexpr u32 NF = 2 * G::N;
-    constexpr bool LAZYFOLD = LAZY != 0 && KX_FOLD;
-    constexpr bool FOLD = KX_FOLD && (LAZY != 0 || KX_STRICT_FOLD);
+    constexpr bool LAZYFOLD = LAZY != 0;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 unit = __builtin_amdgcn_readfirstlane(xcd_item_x(blockIdx.x, gridDim.x));   // (b * nsel + limb number) * 2 + h, XCD-contiguous
@@ -1063,7 +836,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
             for (int r = 0; r < G::E; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
             const size_t at = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
             load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, m);                    // |x| <= 0.7 p, centred
-            mac_keys<G, false, 0, KX_PF, int(NF)>(acc0, acc1, v, key_row<G>(a, i, i) + h * G::N, round_src(first), tid, m);
+            mac_keys<G, false, int(NF)>(acc0, acc1, v, key_row<G>(a, i, i) + h * G::N, round_src(first), tid, m);
         } else {
             mac_keys_first<G, LAZYFOLD, int(NF)>(acc0, acc1, v, a.t_target + (size_t(b) * L + i) * NF + h * G::N, key_row<G>(a, i, i) + h * G::N,
                                                  round_src(first), tid, m);
@@ -1081,10 +854,10 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         if (nit == i) ++nit;
         const double* k0 = key_row<G>(a, it, i) + h * G::N;
         WU::template forward<false, false>(v, ldsx, tid, tb, tb + NF, m, typename WU::NoHook(), typename WU::NoHook(), h);
-        mac_keys<G, FOLD, 0, KX_PF, int(NF)>(acc0, acc1, v, k0, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
+        mac_keys<G, true, int(NF)>(acc0, acc1, v, k0, round_src(nit), tid, m);           // nit <= L: s'_0 follows the last c_d
         it = nit;
     }
-    if constexpr (FOLD && LAZY == 0) {
+    if constexpr (LAZY == 0) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) { acc0[r] = hxf::reduce(acc0[r], m); acc1[r] = hxf::reduce(acc1[r], m); }
     }
@@ -1097,8 +870,8 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         const double* tb = a.tables + toff;
         ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L) + G::N, tid, tb, m, h);
         const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
-        if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP, 0, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
-        else ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
+        if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
+        else ksx_down_round<G, W, -1, SKIP, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
         const double* nxt = round_src(L + 1);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) v[r] = (nxt + G::idxA(r, 0))[u32(tid)];
@@ -1111,19 +884,13 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         const double* tb = a.tables + toff;
         ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L + 1) + G::N, tid, tb, m, h);
         const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
-        if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP, 0, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
-        else ksx_down_round<G, W, -1, SKIP, 0, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
+        if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
+        else ksx_down_round<G, W, -1, SKIP, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
     }
     hxf::report_range(bad, a.range_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
-// HEXL_KSX_DIAG=0: k_ksx_main starts with the d == i term as in rounds 2-3 (tests, comparisons)
-static bool diag_late_enabled() {
-    static const bool on = [] { const char* e = getenv("HEXL_KSX_DIAG"); return !(e && atoi(e) == 0); }();
-    return on;
-}
-
 template <class K>
 static int set_lds_x(K kern, size_t bytes) {
     HX_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1135,14 +902,11 @@ static int set_lds_x(K kern, size_t bytes) {
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
 static int launch_stage_x(hexl_ks_plan* p, const KsArgsX& a, int stage) {
     using G = Geom<LOGN, LOGE>;
-    // the d == i term as the last multiply-accumulate of the mod-up (k_ksx_main<..., DL>): N = 16384 only (measured there), L >= 2
-    constexpr bool CAN_DL = KX_DIAG_LATE && !FUSED && LOGN == 14 && LOGE == 4;
     static PerDeviceOnce once;
     if (int rc0 = once.run(p->ctx->device, [] {
             int rc = set_lds_x(k_ksx_special<LOGN, LOGE, LAZY, SKIP>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksx_intt<LOGN, LOGE, LAZY, FUSED>, G::LDS_USED);
             if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>, G::LDS_USED);
-            if constexpr (CAN_DL) if (!rc) rc = set_lds_x(k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP, true>, G::LDS_USED);
             return rc;
         }))
         return rc0;
@@ -1160,13 +924,8 @@ static int launch_stage_x(hexl_ks_plan* p, const KsArgsX& a, int stage) {
         hipLaunchKernelGGL((k_ksx_intt<LOGN, LOGE, LAZY, FUSED>), grid_for(a.nb * a.nsel), dim3(G::T), G::LDS_USED, st, a);
     if (stage == 2)
         hipLaunchKernelGGL((k_ksx_special<LOGN, LOGE, LAZY, SKIP>), grid_for(a.nb), dim3(G::T), G::LDS_USED, st, a);
-    if (stage == 4) {
-        const dim3 grid = KX_MAIN_PERSIST ? grid_for(a.nb * a.nsel) : dim3(a.nb * a.nsel);
-        bool dl = false;
-        if constexpr (CAN_DL) dl = a.L >= 2 && diag_late_enabled();
-        if constexpr (CAN_DL) if (dl) hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP, true>), grid, dim3(G::T), G::LDS_USED, st, a);
-        if (!dl) hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>), grid, dim3(G::T), G::LDS_USED, st, a);
-    }
+    if (stage == 4)
+        hipLaunchKernelGGL((k_ksx_main<LOGN, LOGE, LAZY, FUSED, SKIP>), dim3(a.nb * a.nsel), dim3(G::T), G::LDS_USED, st, a);
     return 0;
 }
 
@@ -1184,8 +943,6 @@ static int launch_stage_tier(hexl_ks_plan* p, const KsArgsX& a, int stage, int t
             case 6:  return launch_stage_x<14, 4, 3>(p, a, stage);
             default: return launch_stage_x<14, 4, 0>(p, a, stage);
         }
-    } else if constexpr (LOGE == 5) {                              // 32 coefficients x 512 threads: measured slower, kept for study
-        return tier ? launch_stage_x<LOGN, 5, 3, FUSED>(p, a, stage) : launch_stage_x<LOGN, 5, 0, FUSED>(p, a, stage);
     } else {
         if (!tier) return launch_stage_x<LOGN, LOGE, 0, FUSED>(p, a, stage);
         return skip ? launch_stage_x<LOGN, LOGE, 3, FUSED, true>(p, a, stage) : launch_stage_x<LOGN, LOGE, 3, FUSED>(p, a, stage);
@@ -1298,10 +1055,7 @@ size_t hx_ks_x_scratch_words(size_t L) { return L + 2; }   // per instance, in u
 
 // Large chunks of N = 16384 instances: one workgroup per (instance, limb) must fill the chip at least twice, like the
 // fused k_ksf_up of the (b, d)-major pipeline. HEXL_KS_PIPE=1 keeps the (b, d)-major pipeline (tests, comparisons).
-u32 hx_ks_x_loge() {                                              // HEXL_KSX_LOGE=5: 32 coefficients x 512 threads
-    static const int v = [] { const char* e = getenv("HEXL_KSX_LOGE"); return (e && atoi(e) == 5) ? 5 : 4; }();
-    return (u32)v;
-}
+u32 hx_ks_x_loge() { return 4; }                                  // 16 coefficients per thread at every ring dimension
 bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
     static const int pipe = [] { const char* e = getenv("HEXL_KS_PIPE"); return e ? atoi(e) : 2; }();
     if (!p->d_keys_x || p->logn < 10 || p->logn > 15) return false;
@@ -1321,8 +1075,8 @@ bool hx_ks_x_applies(const hexl_ks_plan* p, size_t nb) {
 #ifdef HEXL_PROFILING_AIDS
 static u32 ksx_alias_mask() {
     static const u32 mask = [] {
-        const char *e = getenv("HEXL_KSX_ALIAS"), *k = getenv("HEXL_KSX_KEY_ALIAS");
-        const u32 m = (e ? (u32)atoi(e) : 0u) | ((k && atoi(k) == 1) ? 1u : 0u);
+        const char* e = getenv("HEXL_KSX_ALIAS");
+        const u32 m = e ? (u32)atoi(e) : 0u;
         if (m) fprintf(stderr, "[hexl_mi355x PROFILING BUILD] HEXL_KSX_ALIAS=%u: keyswitch results are WRONG by design\n", m);
         return m;
     }();
@@ -1359,7 +1113,7 @@ int hx_launch_keyswitch_x(hexl_ks_plan* p, u64* d_result, const u64* d_t_target,
         default: return HEXL_E_BADARG;
     }
     // (the kernels' LAZY template argument = forward reduction period of the transforms, f64_arith.hpp: launch_stage_tier)
-    return p->x_loge == 5 ? run_chunk_x<14, 5>(p, a, stage_mask, ev) : run_chunk_x<14, 4>(p, a, stage_mask, ev);
+    return run_chunk_x<14, 4>(p, a, stage_mask, ev);
 }
 
 // fused ciphertext multiply + relinearize for one scratch chunk (always the slot-major pipeline, 16-coefficient geometry).

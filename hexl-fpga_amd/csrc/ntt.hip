@@ -20,12 +20,6 @@
 #ifndef HX_IFWD_PRIO
 #define HX_IFWD_PRIO 1222
 #endif
-#ifndef HX_NTT_NO_SLOW
-#define HX_NTT_NO_SLOW 0   // 1 = TIMING ONLY (wrong results for out-of-range words / bad tables): the persistent fast-path kernels without their
-#endif                     // out-of-line integer fallbacks -- what the presence of those calls costs the FP64 path
-#ifndef HX_IFWD_PERSIST_DEFAULT
-#define HX_IFWD_PERSIST_DEFAULT 0
-#endif
 #include "hexl_internal.hpp"
 #include "ntt_core.hpp"
 #include "ntt_core_f64.hpp"
@@ -35,9 +29,15 @@ constexpr int ntt_fwd_prio(int logn) { return logn == 11 ? 0 : HX_FWD_PRIO; }
 
 using namespace hx;
 
-#ifndef NTT_SEMI_UNI
-#define NTT_SEMI_UNI 1   // the SEMI kernel variants: semi-strict butterflies in the wave-uniform passes only (ntt_core_f64.hpp SEMIU; 0: in every pass)
+// per-lane twiddles of the persistent FP64 transforms requested ahead of their butterflies (ntt_core_f64.hpp WgNttF64 PRE / IPRE, as in
+// keyswitch_x.hip): round-6 experiment knobs
+#ifndef NTT_PRE
+#define NTT_PRE 0
 #endif
+#ifndef NTT_IPRE
+#define NTT_IPRE 0
+#endif
+// (the kernels' SEMI parameter: strict tier with the semi-strict butterflies in the WAVE-UNIFORM passes, ntt_core_f64.hpp SEMIU)
 
 // ---------------------------------------------------------------------------------------------
 // Exact-arithmetic fast path. The Harvey kernels above must be replayed op for op only where that is observable:
@@ -68,17 +68,11 @@ __device__ __forceinline__ bool prepare_entry(const u64* __restrict__ roots, con
 // What a launch needs to know about its tables. The counters come from rings of 64 slots (one per launch, round robin: no memset per
 // launch -- the preparation of launch k zeroes the slots launch k + 32 will use, long after their last reader has finished on this stream).
 struct NttPrep {
-    double* w; double* wp;               // derived tables: written by the preparation, read by the transforms (never restrict / const here)
+    double* w; double* wp;               // derived tables: written by k_ntt_prepare, read by the transforms (never restrict / const here)
     u32* viol; u32* viol_later;          // entries that are not Shoup pairs, this launch's slot / the slot zeroed for launch + 32
-    // fused launches (the persistent grid prepares for itself, ntt_tables_ready): EIGHT copies of the tables, one per XCD, at
-    // w + x * 2 n (its w/p table n further), and per XCD a cache line of its own (NTT_RING_STRIDE words) with a ticket and a ready
-    // counter in words 0 and 1 (ready: slices done in the low half, slices with a bad entry in the high half): ring[x * NTT_RING_STRIDE + k]
-    u32* ring; u32* ring_later;
-    u32 n, fused;
-    u32* redo;                           // N = 32768 half-transform launches: [0] how many polynomials the integer butterflies must redo, [1 ...] which
+    u32 n;
+    u32* redo;                           // launches with a k_ntt_redo_* behind them: [0] how many polynomials the integer butterflies must redo, [1 ...] which
 };
-
-constexpr u32 NTT_RING_STRIDE = 32;       // 128 bytes: the XCDs poll and count in different cache lines
 
 __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restrict__ precon, u64 q, NttPrep pr) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,8 +82,6 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
         pr.w[0] = 0.0;
         *pr.viol_later = 0;
         if (pr.redo) *pr.redo = 0;
-        for (u32 x = 0; x < 8; ++x)
-            for (u32 k = 0; k < 3; ++k) pr.ring_later[x * NTT_RING_STRIDE + k] = 0;
         return;
     }
     // (one atomic per wave that saw a bad entry, not one per entry: random tables -- the reference benchmark's -- fail in every entry)
@@ -97,80 +89,16 @@ __global__ void k_ntt_prepare(const u64* __restrict__ roots, const u64* __restri
     if (__builtin_amdgcn_ballot_w64(!ok) != 0 && (threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(pr.viol, 1u);
 }
 
-// Round 5 (HEXL_NTT_FUSED_PREPARE=1; measured no faster, off by default -- see fused_prepare_enabled): the preparation INSIDE the persistent
-// transform launch. k_ntt_prepare in front of every launch costs 2.8-5.6 us of kernel plus a dispatch gap -- 7-9 % of a 77 us launch at
-// batch 1024. Every workgroup requests its first polynomial, then helps to prepare the tables and waits for them, so the preparation hides
-// behind the first input's latency.
-// One copy of the tables PER XCD, prepared by workgroups of that XCD and read by workgroups of that XCD only (the wave's XCC_ID hardware
-// register says which): the L2 is per XCD and is the coherence point of its own compute units, so a slice whose stores have been
-// acknowledged (s_waitcnt vmcnt(0): the vector L1 is write-through) is visible to every reader of that XCD -- no L2 write-back, no L2
-// invalidate. (A single table shared by all XCDs needs agent-scope release / acquire: buffer_wbl2 + buffer_inv sc1 in every wave --
-// measured, it DOUBLES the launch time: 6.4 M against 12.8 M NTT/s at batch 1024.) The vector L1 and the scalar cache (the transforms read
-// the table through the constant address space) cannot hold stale lines of it: both are invalidated at dispatch and the table is first
-// touched behind the wait; the pointers handed to the transforms are laundered behind the wait so that no load of the table can be
-// scheduled in front of it. Work is claimed by TICKET per XCD (n / T slices of one entry per thread; eight times the verification work
-// of one table, still half an entry per thread): every workgroup takes one ticket of its XCD on arrival and the first n / T of them
-// prepare that slice -- a workgroup only ever waits for slices whose ticket a RUNNING workgroup holds, so nothing depends on
-// co-residency; it does depend on every XCD receiving at least n / T workgroups of the grid (workgroups go to the XCDs round robin:
-// 32 each of a 256-workgroup grid; the launcher checks).
-// (Round 4's variant had EVERY workgroup verify the whole table -- 16 entries per thread: slower, tools/experiments/ntt_fused_prepare.patch.)
-// the XCD (XCC) this wave runs on: hwreg(HW_REG_XCC_ID) bits 3:0 on gfx942 / gfx950 (what HIP's __smid() reads there too)
-__device__ __forceinline__ u32 hx_xcc_id() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return u32(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7u;
-#else
-    return 0u;
-#endif
-}
-
-template <int T>
-__device__ __forceinline__ bool ntt_tables_ready(const NttPrep& pr, const u64* __restrict__ roots, const u64* __restrict__ precon,
-                                                 u64 q, const double*& w, const double*& wp) {
-    double *lw = pr.w, *lwp = pr.wp;
-    if (pr.fused) {
-        const u32 xcc = hx_xcc_id();
-        lw += size_t(xcc) * 2 * pr.n;
-        lwp = lw + pr.n;
-        u32 *ticket = pr.ring + xcc * NTT_RING_STRIDE, *ready = ticket + 1;
-        const u32 slices = pr.n / T;
-        // every workgroup takes ONE ticket of its XCD; the first `slices` of them prepare the slice of that number. (The launcher fuses
-        // only when every XCD is sure to receive at least `slices` workgroups of the grid.)
-        __shared__ u32 claimed;
-        if (threadIdx.x == 0) claimed = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const u32 t = claimed;
-        if (t < slices) {
-            const u32 i = t * T + threadIdx.x;
-            bool ok = true;
-            if (i == 0) {
-                lw[0] = 0.0;                                       // (index 0 is never read by either transform)
-                __hip_atomic_store(pr.viol_later, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (u32 k = 0; k < 3; ++k) __hip_atomic_store(pr.ring_later + xcc * NTT_RING_STRIDE + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                ok = prepare_entry(roots, precon, q, i, lw, lwp);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's entries are in the XCD's L2
-            const bool slice_bad = __syncthreads_or(!ok);           // (the barrier the slice needs anyway: ONE violation count per slice)
-            // ONE atomic says both "slice done" (low half) and "it had an entry that is not a Shoup pair" (high half): two counters would
-            // need an ordering between them
-            if (threadIdx.x == 0) atomicAdd(ready, slice_bad ? 0x10001u : 1u);
-        }
-        __shared__ u32 seen;
-        if (threadIdx.x == 0) {
-            u32 v;
-            while (((v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFFu) < slices) __builtin_amdgcn_s_sleep(8);
-            seen = v;
-        }
-        __syncthreads();
-        const double *cw = lw, *cwp = lwp;
-        asm volatile("" : "+s"(cw), "+s"(cwp) :: "memory");        // every table load depends on these: none moves in front of the wait
-        w = cw; wp = cwp;
-        return (seen >> 16) != 0;
-    }
-    const double *cw = lw, *cwp = lwp;
-    asm volatile("" : "+s"(cw), "+s"(cwp) :: "memory");            // every table load depends on these: none moves in front of the wait
-    w = cw; wp = cwp;
-    return __hip_atomic_load(pr.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;       // counted by k_ntt_prepare, a launch of its own
+// The derived tables of a launch and whether k_ntt_prepare (a launch of its own in front of every fast-path launch: 2.8 us + a dispatch
+// gap) found an entry that is not a Shoup pair. (The preparation INSIDE the persistent transform launch -- per-XCD table copies, ticketed
+// slices -- was built in rounds 4-5, is bit-exact and measured no faster: tools/experiments/ntt_fused_prepare*.patch, README.md.)
+__device__ __forceinline__ bool ntt_tables_ready(const NttPrep& pr, const double*& w, const double*& wp) {
+    // (no laundering of the pointers: rounds 5's fused variant passed them through an asm barrier, which cost them their address space --
+    // every per-lane twiddle load of the persistent kernels became a FLAT load, counted by lgkmcnt as well as vmcnt, so that each
+    // re-deal's LDS wait also waited for the twiddles in flight; found in the ISA in round 6: forward +1.5-2 % at batch 1024, +4 % at
+    // batch 4096 (15.2 M NTT/s = 0.498 of 8 TB/s), inverse +2 % at 4096; profiles/r06_ab_ntt_flat_loads.txt)
+    w = pr.w; wp = pr.wp;
+    return __hip_atomic_load(pr.viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
@@ -282,7 +210,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), (SEMI && !NTT_SEMI_UNI), 0, (SEMI && NTT_SEMI_UNI)>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+    WgNttF64<LOGN, LOGE, LAZY, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -319,7 +247,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
         out_of_range |= raw >= limit;
         f[r] = fast_path_input<LAZY>(raw, m);
     }
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, true>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
     const bool slow = __syncthreads_or(out_of_range);                            // see k_ntt_fwd_x
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
@@ -366,10 +294,7 @@ __device__ __forceinline__ void ntt_note_redo(const NttPrep& prep, u32 p, int ti
 // the sixteen prefetched words of the next polynomial in scratch -- a wait for them in the middle of the transform: 11.3 M against 12.0 M
 // inverse NTT/s at q = 2^52 + 393217, batch 1024, 10.4 M against 11.9 M at batch 4096 with the fallback compiled out (round 5; the lazy
 // kernels and the forward ones spill around the call only and measure the same either way, so they keep the call and save the dispatch).
-#ifndef HX_NTT_INV_REDO
-#define HX_NTT_INV_REDO 1   // 0: A/B variant with the call inside (tools/build_variant.sh)
-#endif
-template <int LOGN, int LAZY> constexpr bool ntt_inv_redo = (HX_NTT_INV_REDO && LOGN == 14 && LAZY == 0);
+template <int LOGN, int LAZY> constexpr bool ntt_inv_redo = (LOGN == 14 && LAZY == 0);
 
 // Persistent variants (the default fast path): one workgroup per CU walks the batch, and the NEXT polynomial's words
 // are requested into 2 E spare registers at the very start of the current transform. A lone 1024-thread workgroup per
@@ -386,7 +311,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
-    // the first polynomial is requested before anything is waited for (fused launches: the table preparation hides behind it)
+    // the first polynomial is requested before anything is waited for
     u64 raw[G::E];
     {
         const int tid = threadIdx.x;
@@ -395,19 +320,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
     }
     const double *w, *wp;
-    const bool bad_tables = ntt_tables_ready<G::T>(prep, roots, precon, q, w, wp);   // counted by the preparation (k_ntt_prepare, or this launch's leading workgroups)
+    const bool bad_tables = ntt_tables_ready(prep, w, wp);   // counted by k_ntt_prepare
     if (bad_tables) {
         // Tables that are not genuine Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42 feeds random ones): known at kernel entry,
         // the same for every polynomial and wave-uniform -- the whole batch goes straight through the integer butterflies.
         // (Rounds 2-3 ran the FP64 transform on every polynomial first and only then fell back: the transform twice.)
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
-#if !HX_NTT_NO_SLOW
 #pragma unroll 1
         for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
             slow_fwd<LOGN, LOGE>(x + size_t(p) * G::N, lds, roots, precon, q);
             __syncthreads();
         }
-#endif
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
@@ -428,15 +351,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), (SEMI && !NTT_SEMI_UNI), 0, (SEMI && NTT_SEMI_UNI)>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, (Geom<LOGN, LOGE>::P >= 3 ? NTT_PRE : 0), (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
         } else {
-#if !HX_NTT_NO_SLOW
             slow_fwd<LOGN, LOGE>(px, lds, roots, precon, q);
             __syncthreads();
-#endif
         }
     }
 }
@@ -459,11 +380,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
     }
     const double *w, *wp;
-    const bool bad_tables = ntt_tables_ready<G::T>(prep, iroots, iprecon, q, w, wp);
+    const bool bad_tables = ntt_tables_ready(prep, w, wp);
     constexpr bool REDO = ntt_inv_redo<LOGN, LAZY>;
     if (bad_tables) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
-#if !HX_NTT_NO_SLOW
         if constexpr (!REDO) {
 #pragma unroll 1
             for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
@@ -471,7 +391,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
                 __syncthreads();
             }
         }
-#endif
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
@@ -493,20 +412,19 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;
         const u64* pnx = x + size_t(pn) * G::N;
         const u32 tB = u32(G::idxB(0, tid));
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, 0, true>::template inverse<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, [&] {   // no w/p table
+        auto request_next = [&] {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
-        });
+        };
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, true>::template inverse<false, decltype(request_next), (NTT_IPRE != 0)>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_next);   // no w/p table
         const bool slow = vote.result(tid);
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
         } else if constexpr (REDO) {
             ntt_note_redo(prep, p, tid);
         } else {
-#if !HX_NTT_NO_SLOW
             slow_inv<LOGN, LOGE>(px, lds, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
             __syncthreads();
-#endif
         }
     }
 }
@@ -529,12 +447,12 @@ __global__ __launch_bounds__(1024) void k_ntt_fwd_h(u64* __restrict__ x, const u
                                                     u64 q, NttPrep prep, u32 batch, NttHint hint) {
     using G = Geom<14, 4>;
     constexpr int FS = LAZY != 0 ? 1 : 0;
-    using W = WgNttF64<14, 4, LAZY, 0, 0, FS, false, ntt_fwd_prio(14), (SEMI && !NTT_SEMI_UNI), 1, (SEMI && NTT_SEMI_UNI)>;
+    using W = WgNttF64<14, 4, LAZY, 0, FS, false, ntt_fwd_prio(14), 1, SEMI>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
     const double *w, *wp;
-    const bool bad_tables = ntt_tables_ready<G::T>(prep, roots, precon, q, w, wp);
+    const bool bad_tables = ntt_tables_ready(prep, w, wp);
     if (bad_tables) {                                                           // see k_ntt_fwd_p; k_ntt_redo_fwd does the batch
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
         return;
@@ -585,12 +503,12 @@ template <int LAZY>
 __global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u64* __restrict__ iroots, const u64* __restrict__ iprecon,
                                                     u64 q, NttPrep prep, hxf::InvScale sc, u32 batch, NttHint hint) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, 0, 0, 0, true, HX_FWD_PRIO, false, 1>;      // no w/p table
+    using W = WgNttF64<14, 4, LAZY, 0, 0, true, HX_FWD_PRIO, 1>;      // no w/p table
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, false);
     const Mod m{(double)q, 1.0 / (double)q};
     const double *w, *wp;
-    const bool bad_tables = ntt_tables_ready<G::T>(prep, iroots, iprecon, q, w, wp);
+    const bool bad_tables = ntt_tables_ready(prep, w, wp);
     if (bad_tables) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *hint.word = hint.tag;
         return;
@@ -652,7 +570,7 @@ __global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u
 #pragma unroll
         for (int r = 0; r < G::E; ++r) {
             double pr2[2] = {u[r], v[r]};
-            inv_stages_f64<2, 0, 1, 14, 15, true, 3, true, 0, true>(pr2, 0u, w, wp, m, sc);
+            inv_stages_f64<2, 0, 1, 14, 15, true, 3, true, true>(pr2, 0u, w, wp, m, sc);
             const double c0 = hxf::lift(pr2[0], m), c1 = hxf::lift(pr2[1], m);
             (px + G::idxA(r, 0))[u32(tid)] = LAZY == 0 ? hxf::from_f64_53(c0) : hxf::from_f64(c0);
             (px + G::N + G::idxA(r, 0))[u32(tid)] = LAZY == 0 ? hxf::from_f64_53(c1) : hxf::from_f64(c1);
@@ -703,13 +621,6 @@ static bool halves_enabled() {
     return v;
 }
 
-static bool semi_enabled() {
-    // round 4's variant (semi-strict butterflies in EVERY pass: twice the per-lane twiddle loads) measured 2-4 % slower and was off; round 5's
-    // runs them in the wave-uniform passes only (NTT_SEMI_UNI, ntt_core_f64.hpp SEMIU: w/p through the scalar cache) and measures +3-4 %
-    // forward (q = 2^52 + 393217: 11.4 -> 11.75 M NTT/s at batch 1024, 12.6 -> 13.15 M at batch 4096, same box): on; HEXL_NTT_SEMI=0 turns it off
-    static const bool v = [] { const char* e = getenv("HEXL_NTT_SEMI"); return !(e && atoi(e) == 0); }();
-    return v;
-}
 static bool fast_path_enabled() {
     static const bool v = [] { const char* e = getenv("HEXL_NTT_INT"); return !(e && atoi(e) == 1); }();
     return v;
@@ -724,11 +635,10 @@ static int ensure_ntt_hint(hexl_ctx* ctx) {                        // NttHint: f
     return 0;
 }
 
-// device scratch for the derived tables: a ring of 64 violation counters (launches with a k_ntt_prepare of their own), a ring of 64 x 24
-// per-XCD counters (fused launches), then eight copies of [w | w/p] (n doubles each; the separate preparation fills copy 0 only)
+// device scratch for the derived tables: a ring of 64 violation counters (one per launch, round robin), then [w | w/p] (n doubles each)
 static int reserve_tables(hexl_ctx* ctx, u64 n, NttPrep* pr) {
-    constexpr size_t HEAD = 256 + 64 * 8 * NTT_RING_STRIDE * sizeof(u32) + 256;       // 64 violation counters, 64 x 8 ring lines
-    const size_t bytes = HEAD + 8 * 2 * n * sizeof(double);
+    constexpr size_t HEAD = 256;                                                        // 64 violation counters
+    const size_t bytes = HEAD + 2 * n * sizeof(double);
     const void* before = ctx->d_ntt_tab;
     int rc = hx_reserve_device(ctx, &ctx->d_ntt_tab, &ctx->d_ntt_tab_bytes, bytes);
     if (rc) return rc;
@@ -740,10 +650,7 @@ static int reserve_tables(hexl_ctx* ctx, u64 n, NttPrep* pr) {
     const u32 seq = ctx->ntt_seq++;
     pr->viol = counters + (seq & 63);
     pr->viol_later = counters + ((seq + 32) & 63);
-    pr->ring = counters + 64 + 8 * NTT_RING_STRIDE * (seq & 63);
-    pr->ring_later = counters + 64 + 8 * NTT_RING_STRIDE * ((seq + 32) & 63);
     pr->n = (u32)n;
-    pr->fused = 0;
     pr->redo = nullptr;
     return 0;
 }
@@ -754,7 +661,6 @@ static unsigned redo_grid(unsigned fast_grid) { return fast_grid < 32u ? fast_gr
 static int reserve_redo(hexl_ctx* ctx, size_t batch, NttPrep* pr) {
     int rc = hx_reserve_device(ctx, &ctx->d_ntt_redo, &ctx->d_ntt_redo_bytes, (batch + 1) * sizeof(u32));
     pr->redo = (u32*)ctx->d_ntt_redo;
-    pr->fused = 0;
     return rc;
 }
 // the preparation as a launch of its own, in front of a transform kernel that does not do it itself
@@ -762,17 +668,6 @@ static int launch_prepare(hexl_ctx* ctx, const u64* roots, const u64* precon, u6
     hipLaunchKernelGGL(k_ntt_prepare, dim3((pr.n + 255) / 256), dim3(256), 0, ctx->stream, roots, precon, q, pr);
     return (int)hipGetLastError();
 }
-// HEXL_NTT_FUSED_PREPARE=1: the persistent kernels prepare the tables themselves (ntt_tables_ready) instead of a k_ntt_prepare launch in
-// front of them. Bit-exact (tests/test_gpu_ntt.py runs the suite both ways), and NOT faster -- measured round 5, three interleaved rounds on
-// one box (profiles/r05_ntt_fused_prepare.txt): forward 12.56-12.76 M against 12.86-12.93 M NTT/s at batch 1024, 13.95-14.18 M against
-// 13.96-14.20 M at batch 4096 (inverse alike). The 2.8 us kernel and its dispatch gap do go away, but every workgroup now sits at a barrier
-// behind its first input and a poll of its XCD's counter before its first butterfly, where the separate launch overlaps the previous
-// launch's tail; the two cost the same. OFF by default: the separate launch stays, as in rounds 2-4.
-static bool fused_prepare_enabled() {
-    static const bool on = [] { const char* e = getenv("HEXL_NTT_FUSED_PREPARE"); return e && atoi(e) == 1; }();
-    return on;
-}
-
 template <int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd(u64* __restrict__ x,
                                                                 const u64* __restrict__ roots,
@@ -863,50 +758,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_ip(u64* __restri
     }
 }
 
-// The forward counterpart (round 4, with the wave priorities of HX_IFWD_PRIO: a persistent forward integer kernel measured slower
-// than one workgroup per polynomial in round 2 and was dropped then). The next polynomial is requested at the top of the current
-// transform, whose first two passes take their twiddles through the scalar cache.
-template <int LOGN, int LOGE>
-__global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_ip(u64* __restrict__ x, const u64* __restrict__ roots,
-                                                                   const u64* __restrict__ precon, u64 q, u32 batch,
-                                                                   const u32* __restrict__ viol = nullptr,
-                                                                   unsigned long long* hint_word = nullptr) {
-    using G = Geom<LOGN, LOGE>;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    if (hint_word && blockIdx.x == 0 && threadIdx.x == 0 && *viol == 0) *hint_word = 0;      // see k_ntt_fwd
-    u64 raw[G::E];
-    {
-        const int tid = threadIdx.x;
-        const u64* p0 = x + size_t(blockIdx.x) * G::N;
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxA(r, 0))[u32(tid)];
-    }
-#pragma unroll 1
-    for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        u64* px = x + size_t(p) * G::N;
-        u64 v[G::E];
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) v[r] = raw[r];
-        const u32 pn = p + gridDim.x < batch ? p + gridDim.x : p;
-        const u64* pnx = x + size_t(pn) * G::N;
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        const u64* tw = roots + opaque_zero();
-        WgNtt<LOGN, LOGE>::forward_lazy(v, lds, tid, tw, precon + (tw - roots), q);
-        WgNtt<LOGN, LOGE>::final_reduce(v, q);
-        const u32 tB = u32(G::idxB(0, tid));
-#pragma unroll
-        for (int r = 0; r < G::E; ++r) (px + G::idxB(r, 0))[tB] = v[r];
-    }
-}
-
 u32 hx_loge_for(u32 logn) {
-    static const int forced = [] { const char* e = getenv("HEXL_NTT_LOGE"); return e ? atoi(e) : 0; }();
     // N = 16384: 16 coefficients per thread x 1024 threads (4 waves/SIMD) measured ~10 % faster than 32 x 512
-    if (logn == 14) return forced == 5 ? 5 : 4;
-    return logn <= 10 ? 4 : 5;
+    return (logn == 14 || logn <= 10) ? 4 : 5;
 }
 
 u32 hx_idxB(u32 logn, u32 r, u32 tid) {
@@ -926,20 +780,8 @@ static int launch_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
             return 0;
         }))
         return rc;
-    // HEXL_NTT_IFWD_PERSIST=1: the persistent forward integer kernel (experiment)
-    static const int persist = [] { const char* e = getenv("HEXL_NTT_IFWD_PERSIST"); return e ? atoi(e) : HX_IFWD_PERSIST_DEFAULT; }();
-    const size_t slots = size_t(ctx->num_cu) * (G::LDS_USED > 80 * 1024 ? 1 : (160 * 1024) / G::LDS_USED);
-    if constexpr (LOGN == 14 && LOGE == 4) if (persist && batch > slots) {
-        static PerDeviceOnce once_p;
-        if (int rc = once_p.run(ctx->device, [] {
-                HX_CHECK(hipFuncSetAttribute((const void*)k_ntt_fwd_ip<LOGN, LOGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED));
-                return 0;
-            }))
-            return rc;
-        hipLaunchKernelGGL((k_ntt_fwd_ip<LOGN, LOGE>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED, ctx->stream, x, roots, precon,
-                           q, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
-        return (int)hipGetLastError();
-    }
+    // (a persistent forward integer kernel measured no faster in rounds 2 and 4 -- the integer butterflies are bound by their instruction
+    // count, the prefetch registers cost what the hidden load latency gains -- and is gone)
     hipLaunchKernelGGL((k_ntt_fwd<LOGN, LOGE>), dim3((unsigned)batch), dim3(G::T), G::LDS_USED, ctx->stream, x,
                        roots, precon, q, (u32)batch, ctx->ntt_clear_viol, ctx->ntt_clear_viol ? ctx->ntt_hint_word : nullptr);
     return (int)hipGetLastError();
@@ -993,11 +835,7 @@ static int launch_fwd_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, c
                 return 0;
             }))
             return rc;
-        // the persistent grid prepares the tables itself (its first n / T workgroups, ntt_tables_ready) -- decided HERE, where the
-        // persistent branch is taken (round 4's experiment re-derived that condition elsewhere)
-        pr.fused = fused_prepare_enabled() && slots / 8 >= pr.n / G::T ? 1u : 0u;   // every XCD receives slots / 8 workgroups
-        if (!pr.fused)
-            if (int rc = launch_prepare(ctx, roots, precon, q, pr)) return rc;
+        if (int rc = launch_prepare(ctx, roots, precon, q, pr)) return rc;
         hipLaunchKernelGGL((k_ntt_fwd_p<LOGN, LOGE, LAZY, SEMI>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
                            roots, precon, q, pr, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         return (int)hipGetLastError();
@@ -1027,7 +865,6 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
                 return 0;
             }))
             return rc;
-        pr.fused = fused_prepare_enabled() && slots / 8 >= pr.n / G::T ? 1u : 0u;   // see launch_fwd_x
         if constexpr (ntt_inv_redo<LOGN, LAZY>) {                                // fallback in a launch of its own behind the fast kernel
             static PerDeviceOnce once_r;
             if (int rc = once_r.run(ctx->device, [] {
@@ -1035,10 +872,9 @@ static int launch_inv_x(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, cons
                     return 0;
                 }))
                 return rc;
-            if (int rc = reserve_redo(ctx, batch, &pr)) return rc;               // (the preparation zeroes the counter: no fused preparation here)
+            if (int rc = reserve_redo(ctx, batch, &pr)) return rc;               // (the preparation zeroes the counter)
         }
-        if (!pr.fused)
-            if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
+        if (int rc = launch_prepare(ctx, ir, ip, q, pr)) return rc;
         hipLaunchKernelGGL((k_ntt_inv_p<LOGN, LOGE, LAZY>), dim3((unsigned)slots), dim3(G::T), G::LDS_USED + RangeVote::BYTES, ctx->stream, x,
                            ir, ip, q, a, ap, b, bp, pr, sc, (u32)batch, NttHint{ctx->ntt_hint_word, ctx->ntt_hint_tag});
         if constexpr (ntt_inv_redo<LOGN, LAZY>)
@@ -1173,8 +1009,8 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
             if (logn == 14 && period == 6) return launch_fwd_x<14, 4, 6>(ctx, x, batch, roots, precon, q, pr);
             if (period) return dispatch_fwd_x<3>(logn, ctx, x, batch, roots, precon, q, pr);
             // strict tier: semi-strict butterflies (f64_arith.hpp ct_bfly_semi, 11 instead of 14 instructions) in the wave-uniform passes up to
-            // 2^52 (1 + 2^-20) -- SURVEY 8d's q = 2^52 + 393217 included --, the plain strict ones above and with HEXL_NTT_SEMI=0
-            return semi_enabled() && (double)q <= hxf::SEMI_MAX_MODULUS ? dispatch_fwd_x<0, true>(logn, ctx, x, batch, roots, precon, q, pr)
+            // 2^52 (1 + 2^-20) -- SURVEY 8d's q = 2^52 + 393217 included --, the plain strict ones above
+            return (double)q <= hxf::SEMI_MAX_MODULUS ? dispatch_fwd_x<0, true>(logn, ctx, x, batch, roots, precon, q, pr)
                                                                         : dispatch_fwd_x<0>(logn, ctx, x, batch, roots, precon, q, pr);
         }
     }
@@ -1183,9 +1019,7 @@ int hx_launch_ntt_fwd(hexl_ctx* ctx, u64* x, size_t batch, const u64* roots, con
         case 11: return launch_fwd<11, 5>(ctx, x, batch, roots, precon, q);
         case 12: return launch_fwd<12, 5>(ctx, x, batch, roots, precon, q);
         case 13: return launch_fwd<13, 5>(ctx, x, batch, roots, precon, q);
-        case 14:
-            return hx_loge_for(14) == 4 ? launch_fwd<14, 4>(ctx, x, batch, roots, precon, q)
-                                        : launch_fwd<14, 5>(ctx, x, batch, roots, precon, q);
+        case 14: return launch_fwd<14, 4>(ctx, x, batch, roots, precon, q);
         case 15: return launch_fwd<15, 5>(ctx, x, batch, roots, precon, q);
         default: return HEXL_E_BADARG;
     }
@@ -1217,9 +1051,7 @@ int hx_launch_ntt_inv(hexl_ctx* ctx, u64* x, size_t batch, const u64* ir, const 
         case 11: return launch_inv<11, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
         case 12: return launch_inv<12, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
         case 13: return launch_inv<13, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
-        case 14:
-            return hx_loge_for(14) == 4 ? launch_inv<14, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp)
-                                        : launch_inv<14, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
+        case 14: return launch_inv<14, 4>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
         case 15: return launch_inv<15, 5>(ctx, x, batch, ir, ip, q, a, ap, b, bp);
         default: return HEXL_E_BADARG;
     }

@@ -20,21 +20,17 @@ typedef const __attribute__((address_space(4))) double* ctw_t;
 // LAZY = forward reduction period (0: strict; 3, 6 or 12 by modulus size, f64_arith.hpp): butterflies skip the range reduction except after every LAZY-th
 // global stage and after the last one (bounds in f64_arith.hpp). LOGN is only needed to find the last stage.
 // UNI: the twiddle index is wave-uniform (scalar loads through the constant address space)
-// TF > 0 (register-tight kernels, keyswitch_x.hip): per-lane twiddles of a stage with more than TF of them stream
-// through a ring of TF registers, requested TF sub-blocks ahead, with a scheduling barrier every TF sub-blocks. Left
-// alone the compiler requests all 2^u twiddles of a stage (all 31 of a five-stage pass) up front: ~60 registers that
-// a kernel holding 128 accumulator registers does not have (it spilled a quarter of the accumulators for good).
 // SHIFT: phase of the reduction schedule (f64_arith.hpp lazy_fwd_reduce_after; 1 = un-centred inputs taken as they are)
 // NORED: global stage whose PERIODIC reduction is dropped (0 = none): on the shifted schedule the last stage of a 2^14-point
 // transform is a periodic reduction point ((14 + 1) % 3 == 0); a transform whose consumer takes an un-reduced tail (FINAL = false)
 // drops it and hands over three un-reduced stages, 3.45p, instead (f64_arith.hpp)
 // SEMI (strict kernels only, LAZY == 0): the semi-strict schedule of f64_arith.hpp ct_bfly_semi -- Shoup-form products (the w/p table
 // IS read here) and outputs reduced only where the next stage adds them; the last stage of the call reduces everything.
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int TF = 0, int SHIFT = 0, int NORED = 0, bool SEMI = false>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int SHIFT = 0, int NORED = 0, bool SEMI = false>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
     if constexpr (SEMI) {
-        static_assert(LAZY == 0 && TF == 0, "semi-strict schedule: strict kernels, no twiddle ring");
+        static_assert(LAZY == 0, "semi-strict schedule: strict kernels");
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             const u32 base = (1u << (S0 - 1 + u)) + (G << u);
@@ -57,29 +53,15 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
         const bool red = !LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED);
-        constexpr int TFR = TF > 0 ? TF : 1;
-        const bool ring = TF > 0 && !UNI && (1 << u) > TF;
-        double Wq[TFR];
-        if (ring) {
-#pragma unroll
-            for (int j = 0; j < TFR; ++j) Wq[j] = w[base + j];
-        }
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
-            double W;
-            if (ring) {
-                W = Wq[j % TFR];
-                if (j + TFR < (1 << u)) Wq[j % TFR] = w[base + j + TFR];
-            } else {
-                W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
-            }
+            const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
                 if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
                 else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
             }
-            if (ring && (j % TFR) == TFR - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -145,7 +127,7 @@ __device__ __forceinline__ void inv_bfly(double& X, double& Y, double W, double 
     }
 }
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, int TF = 0, bool NOWP = false>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, bool NOWP = false>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -153,20 +135,10 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
     for (int u = 0; u < K; ++u) {
         const bool fused = LAST && (u == K - 1);
         const u32 base = N - (N >> (LO + u)) + 1 + (G << (K - 1 - u));
-        constexpr int TFR = TF > 0 ? TF : 1;
-        const bool ring = TF > 0 && !UNI && !fused && (1 << (K - 1 - u)) > TF;       // see fwd_stages_f64
-        double Wq[TFR], Wpq[TFR];
-        if (ring) {
-#pragma unroll
-            for (int j = 0; j < TFR; ++j) { Wq[j] = iw[base + j]; Wpq[j] = NOWP ? 0.0 : iwp[base + j]; }
-        }
 #pragma unroll
         for (int j = 0; j < (1 << (K - 1 - u)); ++j) {
             double W = 0, Wp = 0;
-            if (ring) {
-                W = Wq[j % TFR]; Wp = Wpq[j % TFR];
-                if (j + TFR < (1 << (K - 1 - u))) { Wq[j % TFR] = iw[base + j + TFR]; if (!NOWP) Wpq[j % TFR] = iwp[base + j + TFR]; }
-            } else if (!fused) {
+            if (!fused) {
                 W = UNI ? ((ctw_t)iw)[base + j] : iw[base + j];
                 if (!NOWP) Wp = UNI ? ((ctw_t)iwp)[base + j] : iwp[base + j];
             }
@@ -182,7 +154,6 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
                     v[a1] = hxf::reduce(hxf::mul_shoup(d, sc.nw, sc.nw_p, m), m);
                 }
             }
-            if (ring && (j % TFR) == TFR - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -274,9 +245,6 @@ __device__ __forceinline__ void hx_inv_prio() {
         __builtin_amdgcn_s_setprio(d - 1);
     }
 }
-#ifndef HX_KEEP_LAST_REDUCE
-#define HX_KEEP_LAST_REDUCE 0   // 1: A/B variant that keeps the periodic reduction on the last stage of the shifted schedule
-#endif
 // FSHIFT: phase of the forward reduction schedule (1: un-centred inputs, f64_arith.hpp); NOWP: inverse transforms without
 // the w/p table
 // TOP > 0 (round 5: the slot-major keyswitch at N = 32768): this workgroup transforms ONE of the 2^TOP blocks of a 2^(LOGN + TOP)-point
@@ -287,13 +255,11 @@ __device__ __forceinline__ void hx_inv_prio() {
 // SEMIU (strict kernels, round 5): the semi-strict schedule in the passes whose twiddles are WAVE-UNIFORM only (the first pass and every
 // pass with LO >= 6: for N = 16384 eight of the fourteen stages) -- there w and w/p come through the scalar cache, so the second table costs
 // no vector loads, no registers and does not disturb the per-lane passes' early twiddle requests (PRE), which is what made the all-passes
-// variant (SEMI) lose. The schedule is pass-local (f64_arith.hpp ct_bfly_semi: a pass starts from reduced values and its last stage
+// variant of round 4 lose. The schedule is pass-local (f64_arith.hpp ct_bfly_semi: a pass starts from reduced values and its last stage
 // reduces everything), so strict and semi-strict passes mix freely.
-template <int LOGN, int LOGE, int LAZY = 0, int TF = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, bool SEMI = false, int TOP = 0,
-          bool SEMIU = false>
+template <int LOGN, int LOGE, int LAZY = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, int TOP = 0, bool SEMIU = false>
 struct WgNttF64 {
-    static_assert(!SEMI || (LAZY == 0 && PRE == 0 && TF == 0), "semi-strict forward transforms: strict kernels, plain twiddle loads");
-    static_assert(!SEMIU || (LAZY == 0 && TF == 0 && !SEMI), "semi-strict uniform passes: strict kernels");
+    static_assert(!SEMIU || LAZY == 0, "semi-strict uniform passes: strict kernels");
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
     static constexpr int FLOGN = LOGN + TOP;                      // log2 of the full transform
@@ -324,8 +290,8 @@ struct WgNttF64 {
             const u32 Gl = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             const u32 Gp = gfwd<PASS * LOGE + 1>(top, Gl);
             if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, FSHIFT>(v, Gp, w, m);
-            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, (PASS == 0 || LO >= 6), TF, FSHIFT, 0,
-                                (SEMI || (SEMIU && (PASS == 0 || LO >= 6)))>(v, Gp, w, wp, m);
+            else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, (PASS == 0 || LO >= 6), FSHIFT, 0,
+                                (SEMIU && (PASS == 0 || LO >= 6))>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
                 constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;
@@ -362,8 +328,8 @@ struct WgNttF64 {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = gfwd<(G::P - 1) * LOGE + 1>(top, u32(G::grpB(GRP, tid)));
             // LOGN = 0 tells the stage loop that no stage is the last one
-            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, false, TF, FSHIFT,
-                           (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? FLOGN : 0, SEMI>(v, Gbits, w, wp, m);
+            fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, false, FSHIFT,
+                           (!FINAL && FSHIFT != 0) ? FLOGN : 0>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m, top);
         }
     }
@@ -371,7 +337,7 @@ struct WgNttF64 {
     __device__ static __forceinline__ void fwd_last_tw(double (&v)[E], const double (&tl)[G::NG][(1 << G::KL) - 1], const Mod m) {
         if constexpr (GRP < G::NG) {
             fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, FSHIFT,
-                              (!FINAL && FSHIFT != 0 && !HX_KEEP_LAST_REDUCE) ? FLOGN : 0>(v, tl[GRP], m);
+                              (!FINAL && FSHIFT != 0) ? FLOGN : 0>(v, tl[GRP], m);
             fwd_last_tw<GRP + 1, FINAL>(v, tl, m);
         }
     }
@@ -391,7 +357,7 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, false, 0, FSHIFT>(v, Gp, w, wp, m);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, false, FSHIFT>(v, Gp, w, wp, m);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
                 redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },
@@ -411,7 +377,7 @@ struct WgNttF64 {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = ginv<0, G::KL>(top, u32(G::grpB(GRP, tid)));
             if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, NOWP>(v, Gbits, iw, iwp, m, sc);
-            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, false, TF, NOWP>(v, Gbits, iw, iwp, m, sc);
+            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, false, NOWP>(v, Gbits, iw, iwp, m, sc);
             inv_first<GRP + 1, IPRE>(v, tid, iw, iwp, m, sc, top);
         }
     }
@@ -434,7 +400,7 @@ struct WgNttF64 {
             const u32 Gp = ginv<LO, LOGE>(top, Gl);
             // (TOP > 0: the transform's last stage -- the one with n^-1 folded in -- is not among these)
             if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, FLOGN, false, LAZY, NOWP>(v, Gp, iw, iwp, m, sc);
-            else inv_stages_f64<E, 0, LOGE, LO, FLOGN, (PASS == G::P - 2 && TOP == 0), LAZY, (PASS == G::P - 2 || LO >= 6), TF, NOWP>(v, Gp, iw, iwp, m, sc);
+            else inv_stages_f64<E, 0, LOGE, LO, FLOGN, (PASS == G::P - 2 && TOP == 0), LAZY, (PASS == G::P - 2 || LO >= 6), NOWP>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform, top);
         }
     }

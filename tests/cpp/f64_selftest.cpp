@@ -103,7 +103,7 @@ static void test_transforms(uint64_t n, uint64_t p) {
 // tier, keys up to p/2, both random and pinned at the extremes with the signs that push the accumulator outwards
 static double g_fold_max = 0;
 static double g_fold_strict_max = 0, g_fold_strict_inner = 0;
-// the STRICT tier of mac_fold (keyswitch_x.hip KX_STRICT_FOLD): moduli up to 2^52, x a reduced transform output, the first accumulator
+// the STRICT tier of mac_fold (keyswitch_x.hip, strict kernels): moduli up to 2^52, x a reduced transform output, the first accumulator
 // the reduced d == i term; tracks the accumulator and the two intermediates whose exactness the fma / the addition rely on
 static void test_mac_fold_strict(uint64_t p) {
     hxf::Mod m{(double)p, 1.0 / (double)p};

@@ -26,6 +26,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("FAKE_DEVICES"); *n = e ? atoi(e) : 8; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipDeviceGetPCIBusId(char* b, int len, int) { if (len > 0) b[0] = 0; return hipSuccess; }   // (no sysfs node: no pinning)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));
     strcpy(p->name, "CPU staging model (tests/cpp/hip_shim)"); strcpy(p->gcnArchName, "none");

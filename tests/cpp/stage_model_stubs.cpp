@@ -21,6 +21,7 @@ int hx_launch_keyswitch(hexl_ks_plan* p, u64*, const u64*, size_t batch, int, hi
 }
 int hx_launch_multiply_relinearize(hexl_ks_plan*, u64*, const u64*, const u64*, size_t) { return 0; }
 bool hx_ks_can_overwrite(const hexl_ks_plan*, size_t) { return false; }
+size_t hx_ks_chunk(const hexl_ks_plan*) { return 256; }
 bool hx_ks_lat_applies(const hexl_ks_plan*, size_t) { return false; }     // (the zero-copy lone path needs a device that publishes its limbs)
 u32 hx_ks_x_loge() { return 4; }
 size_t hexl_ks_scratch_bytes(const hexl_ks_plan*, size_t) { return 0; }

@@ -113,7 +113,13 @@ def test_key_stream_split_is_a_same_kernel_difference():
     d = bench.key_stream_split(14.43e6, 9.41e6)
     assert abs(d["key_stream_bytes_per_keyswitch"] - 5.02e6) < 1 and d["dram_side_estimate_bytes_per_keyswitch"] == 9.41e6
     mk = (ROOT / "hexl-fpga_amd" / "csrc" / "Makefile").read_text()
-    assert "libhexl_mi355x_keyalias.so: $(KOBJS) $(OUT)/alias_knob_keys.o" in mk and "OBJS     = $(KOBJS) $(OUT)/alias_knob.o" in mk
+    tmk = (ROOT / "tools" / "Makefile").read_text()
+    assert "OBJS     = $(KOBJS) $(OUT)/alias_knob.o $(OUT)/host_simd.o" in mk
+    # round 6: the variants are built by tools/Makefile into tools/lib_var/, never beside the shipped library
+    assert "keyalias" not in mk.split("all:")[1].split("\n")[0] and "_prof.so" not in mk.split("all:")[1].split("\n")[0]
+    assert "$(VAR)/libhexl_mi355x_keyalias.so: $(KOBJS) $(LIB)/host_simd.o $(VAR)/alias_knob_keys.o" in tmk
+    kobjs = [l for l in tmk.splitlines() if l.startswith("KOBJS")][0]
+    assert all(f"$(LIB)/{o}.o" in kobjs for o in ("ntt", "dyadic", "keyswitch", "keyswitch_f64", "keyswitch_lat", "keyswitch_x", "capi"))
     knob = (ROOT / "hexl-fpga_amd" / "csrc" / "alias_knob.hip").read_text()
     assert "#ifdef HEXL_KEY_ALIAS_KNOB" in knob and "return 0u;" in knob          # the shipped variant reads no environment variable
     assert "getenv" not in knob.split("#else")[1]

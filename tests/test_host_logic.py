@@ -144,3 +144,37 @@ def test_dyadic_batch(api, orc):
     assert api.fake.calls == [("dyadic", 3, n, nm)]
     for k in range(3):
         assert np.array_equal(out[k], orc.dyadic(a[k], b[k], n, mod))
+
+
+def test_host_accumulate_every_simd_level_matches_numpy(hx):
+    """the host's `result += output` (hexl-fpga_amd/csrc/host_simd.cpp; FPGAObject_KeySwitch::fill_out_data, fpga.cpp:441-475): the AVX-512 and
+    AVX2 bodies this CPU can run against numpy on canonical words of a 27-, a 52- and a 62-bit modulus, with ragged lengths (vector tails),
+    boundary values (sum == q - 1, q, 2q - 2) and unaligned starts. No GPU involved: the symbols are plain host code of the C-ABI library."""
+    import ctypes
+    hx.build()
+    lib = ctypes.CDLL(str(hx.LIB_PATH))
+    at_level = getattr(lib, "_Z23hx_add_mod_u64_at_levelPmPKmmmi")
+    at_level.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int]
+    at_level.restype = None
+    auto = getattr(lib, "_Z14hx_add_mod_u64PmPKmmm")
+    auto.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64]
+    auto.restype = None
+    level = getattr(lib, "_Z16hx_add_mod_levelv")
+    level.restype = ctypes.c_int
+    best = level()
+    assert 0 <= best <= 2
+    rng = np.random.default_rng(3)
+    for q in (133857281, 4503599626682369, 4611686018427322369):
+        for n in (1, 7, 16, 33, 16384 + 5):
+            r = rng.integers(0, q, n + 1, dtype=np.uint64)
+            o = rng.integers(0, q, n + 1, dtype=np.uint64)
+            r[1:4] = (q - 1, q - 1, 0)[: max(0, min(3, n))] if n >= 3 else r[1:4]
+            o[1:4] = (q - 1, 1, q - 1)[: max(0, min(3, n))] if n >= 3 else o[1:4]
+            want = ((r[1:].astype(object) + o[1:].astype(object)) % q).astype(np.uint64)
+            for lv in range(best + 1):
+                got = r.copy()
+                at_level(got[1:].ctypes.data, o[1:].ctypes.data, n, q, lv)        # (start 8 bytes off the allocation's alignment)
+                assert got[0] == r[0] and np.array_equal(got[1:], want), (q, n, lv)
+            got = r.copy()
+            auto(got[1:].ctypes.data, o[1:].ctypes.data, n, q)
+            assert np.array_equal(got[1:], want)

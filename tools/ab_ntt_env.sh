@@ -1,6 +1,6 @@
 #!/bin/bash
 # ab_ntt_env.sh <out> <VAR=value> -- standalone NTT rates (bench.time_ntt: N = 16384, batch 1024 and 4096, 300 launches) with and without
-# one environment knob, three interleaved rounds on one box (e.g. HEXL_NTT_FUSED_PREPARE=0: the separate k_ntt_prepare launch)
+# one environment knob, three interleaved rounds on one box (e.g. HEXL_NTT_PERSIST=0: one workgroup per polynomial)
 OUT=$1; KNOB=$2
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $(dirname $OUT); : > $OUT

@@ -15,6 +15,6 @@ for f in ntt dyadic keyswitch keyswitch_f64 keyswitch_lat keyswitch_x capi; do
     OBJS="$OBJS $L/$f.o"
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libhexl_mi355x.so -o $O/libhexl_mi355x.so $OBJS $L/alias_knob.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libhexl_mi355x.so -o $O/libhexl_mi355x.so $OBJS $L/alias_knob.o $L/host_simd.o
 rm -f $O/*.o
 echo "built $O/libhexl_mi355x.so ($*)"

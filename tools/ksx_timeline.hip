@@ -4,9 +4,6 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ihexl-fpga_amd/csrc -Iinclude tools/ksx_timeline.hip -o tools/ksx_timeline
 //   tools/ksx_timeline [nb=256] [L=7]
 #define KX_TIMELINE 1
-#ifndef KX_TL_DL
-#define KX_TL_DL 0   // 1: k_ksx_main<..., DL> (the d == i term last)
-#endif
 #include "keyswitch_x.hip"
 
 #include <algorithm>
@@ -74,7 +71,7 @@ int main(int argc, char** argv) {
     }
     // the kernels bench.py's workload runs: lazy period 3, SKIP (moduli of one size: no range reduction of c_d / s')
     auto ksp = k_ksx_special<14, KX_LOGE, 3, true>;
-    auto kmn = k_ksx_main<14, KX_LOGE, 3, false, true, (KX_TL_DL != 0)>;
+    auto kmn = k_ksx_main<14, KX_LOGE, 3, false, true>;
     hipFuncSetAttribute((const void*)ksp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
     hipFuncSetAttribute((const void*)kmn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_USED);
     const int W = G::T / 64;
@@ -85,7 +82,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             hipMemset(dst, 0, nst * 8);
             hipEventRecord(e0);
-            if (which) hipLaunchKernelGGL(kmn, dim3(KX_MAIN_PERSIST ? 256u : grid), dim3(G::T), G::LDS_USED, 0, a);
+            if (which) hipLaunchKernelGGL(kmn, dim3(grid), dim3(G::T), G::LDS_USED, 0, a);
             else       hipLaunchKernelGGL(ksp, dim3(grid), dim3(G::T), G::LDS_USED, 0, a);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);

@@ -98,8 +98,13 @@ int main(int argc, char** argv) {
     // GeneratePrimes(8, 51, 16384) of the reference's test utilities: 51-bit primes, 1 mod 2n
     const uint64_t primes[8] = {2251799814045697ull, 2251799814799361ull, 2251799814930433ull, 2251799815094273ull,
                                 2251799815487489ull, 2251799815520257ull, 2251799816273921ull, 2251799816568833ull};
+    // HEXL_WORKLOAD_PRIMES=top52: the LARGEST 52-bit primes = 1 mod 2n (what SEAL's CoeffModulus::Create(n, {52, ...}) picks): the strict
+    // FP64 tier -- its counters beside the lazy tier's
+    const uint64_t top52[8] = {4503599626682369ull, 4503599626321921ull, 4503599625830401ull, 4503599625535489ull,
+                               4503599625404417ull, 4503599624847361ull, 4503599624716289ull, 4503599623864321ull};
+    const bool strict = getenv("HEXL_WORKLOAD_PRIMES") && std::string(getenv("HEXL_WORKLOAD_PRIMES")) == "top52";
     if (L < 1 || K > 8 || !batch) { std::fprintf(stderr, "usage: pmc_workload <batch> <L <= 7> [reps] [ntt]\n"); return 2; }
-    std::vector<uint64_t> moduli(primes, primes + K), msf(K, 1);
+    std::vector<uint64_t> moduli(strict ? top52 : primes, (strict ? top52 : primes) + K), msf(K, 1);
     for (uint64_t i = 0; i + 1 < K; ++i) msf[i] = powmod(moduli[K - 1] % moduli[i], moduli[i] - 2, moduli[i]);
     hexl_ctx* ctx = nullptr;
     CK(hexl_ctx_create(0, &ctx));

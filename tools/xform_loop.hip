@@ -22,7 +22,7 @@ using namespace hx;
 #define XL_LOGE 4
 #endif
 using G = Geom<14, XL_LOGE>;
-using W = WgNttF64<14, XL_LOGE, 3, 0, XL_PRE, 1>;
+using W = WgNttF64<14, XL_LOGE, 3, XL_PRE, 1>;
 
 __global__ __launch_bounds__(G::T, XL_LOGE == 4 ? 4 : 2) void k_loop(const double* tables, double* out, Mod m, int rounds, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
