@@ -216,7 +216,7 @@ def cpu_baseline(orc_mod, case, budget_s=24.0):
                       f"-fopenmp; Intel HEXL itself is not in the image"}
 
 
-def cxx_api_end_to_end(L, timeout_s=120):
+def cxx_api_end_to_end(L, timeout_s=120, local_cpulist=None):
     """SURVEY 8d's end-to-end leg: the reference's public C++ API (intel::hexl::KeySwitch on host pointers: pack, PCIe up, kernels,
     PCIe down, host accumulate) at the worksizes of benchmark/micro_keyswitch.sh (1 / 16 / 128; bench_keyswitch.cpp:113-131,153-158),
     measured by tests/cpp/bench_cxx_api in its own process. These rates include PCIe and host copies: reported, never `value`."""
@@ -232,6 +232,18 @@ def cxx_api_end_to_end(L, timeout_s=120):
             out[f"worksize_{ws}"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-200:]}
         except Exception as e:                                       # a reported extra: never fails the benchmark
             out[f"worksize_{ws}"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+    # the same window with the CALLER on the GPU's socket (taskset to the device's local CPUs): the staging slabs and the library's copy
+    # threads live there, and a caller whose arrays were first touched on the other socket pays the inter-socket links for every byte
+    # (round 6, profiles/r06_host_numa_sweep.txt)
+    if local_cpulist:
+        try:
+            import shutil
+            if shutil.which("taskset"):
+                r = subprocess.run(["taskset", "-c", local_cpulist, str(exe), "128", str(L), "0", "1"], capture_output=True, text=True, timeout=timeout_s)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["worksize_128_caller_on_the_gpus_socket"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:
+            out["worksize_128_caller_on_the_gpus_socket"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     # the reference's own SEAL workload at the bridge's worksize 1: relinearise (6 of 7 key moduli) and rotate (5 of 7), chain 52,30,30,40,27,27,27
     for name, Lx in (("seal_chain_relinearize_L6_K7_worksize_1", 6), ("seal_chain_rotate_L5_K7_worksize_1", 5)):
         try:
@@ -301,6 +313,18 @@ def seal_chain_rows(hx, ctx, orc_mod, dev, batch=2048, lone_launches=2000):
         row["speedup_lone"] = row["plan_wide_tier"]["lone_keyswitch_us"] / row["per_limb_tiers"]["lone_keyswitch_us"]
         rows[name] = row
     return rows
+
+
+def gpu_local_cpulist(torch_device_index):
+    """the CPUs of the socket GPU `torch_device_index` hangs off (sysfs local_cpulist of its PCI device), or None"""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(torch_device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        txt = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
+        return txt or None
+    except Exception:
+        return None
 
 
 class PowerSampler:
@@ -745,7 +769,7 @@ def main():
             extra["ntt_N16384_batch1024_refbench_random_tables"] = time_ntt(hx, ctx, orc_mod, dev, 1024, 100, q=NTT_Q_REFBENCH, random_tables=True)
             # beyond the reference's envelope: N = 32768 as two 16384-point sub-transforms per polynomial (ntt.hip k_ntt_fwd_h / k_ntt_inv_h)
             extra["ntt_N32768_batch512_two_sub_transforms"] = time_ntt(hx, ctx, orc_mod, dev, 512, 60, n=32768)
-            extra["cxx_api_end_to_end"] = cxx_api_end_to_end(6)
+            extra["cxx_api_end_to_end"] = cxx_api_end_to_end(6, local_cpulist=gpu_local_cpulist(local))
             extra["dyadic_n8192_m4_batch4096"] = time_dyadic(hx, ctx, orc_mod, dev)
             def other_shape(Lx, Kx, moduli=None, n=N):
                 cs = KsCase(orc_mod, n, Lx, Kx, seed=99, moduli=moduli)

@@ -655,7 +655,21 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     rc = hx_reserve_device(c, &c->d_stage, &c->d_stage_bytes, 2 * dset);
     if (!rc) rc = hx_reserve_pinned(c, &c->h_stage, &c->h_stage_bytes, 2 * in_slab + HOUT * out_slab);
     if (rc) return rc;
-    const size_t nsub = (batch + S - 1) / S;
+    // Sub-batch sizes: S each, but from 64 objects up the window OPENS with S/4 and S/2 and CLOSES with S/2 and S/4: the first upload +
+    // kernels + download and the last unpack are exposed (nothing to overlap with), and they shrink with their sub-batch -- in steady
+    // state the pipeline runs at the PCIe download rate (round 6: 16 objects per 0.55 ms at L = 6 = 45 GB/s), so a window costs that
+    // plus ramp and tail (worksize 128: 1.2 ms of ramp with eight equal sub-batches)
+    std::vector<size_t> sub_first, sub_cnt;
+    {
+        std::vector<size_t> head, tail;
+        if (batch >= 64 && S >= 8) { head = {S / 4, S / 2}; tail = {S / 2, S / 4}; }
+        size_t at = 0, closing = 0;
+        for (size_t t : tail) closing += t;
+        for (size_t h : head) { sub_first.push_back(at); sub_cnt.push_back(h); at += h; }
+        while (at + closing < batch) { const size_t cnt = std::min(S, batch - closing - at); sub_first.push_back(at); sub_cnt.push_back(cnt); at += cnt; }
+        for (size_t t : tail) { sub_first.push_back(at); sub_cnt.push_back(t); at += t; }
+    }
+    const size_t nsub = sub_first.size();
     auto h_in = [&](size_t k) { return (char*)c->h_stage + (k & 1) * in_slab; };
     auto d_in = [&](size_t k) { return (char*)c->d_stage + (k & 1) * dset; };
     auto h_out = [&](size_t k) { return (char*)c->h_stage + 2 * in_slab + (k % HOUT) * out_slab; };
@@ -687,14 +701,14 @@ static int run_pipeline(hexl_ctx* c, size_t batch, const PipeShape& sh,
     } drain{lane, last_ticket};
     for (size_t it = 0; it < nsub + 2; ++it) {
         if (it >= 2) {                                            // drain sub-batch it-2 (frees slab set it&1)
-            const size_t k = it - 2, first = k * S, cnt = std::min(S, batch - first);
+            const size_t k = it - 2, first = sub_first[k], cnt = sub_cnt[k];
             HX_CHECK(hipEventSynchronize(c->ev_down[k & 1]));
             stamp("download complete", k);
             const char* src = h_out(k);
             last_ticket = ticket[k % HOUT] = lane.post([&unpack, &stamp, first, cnt, src, k] { unpack(first, cnt, src); stamp("unpacked", k); });
         }
         if (it < nsub) {
-            const size_t first = it * S, cnt = std::min(S, batch - first);
+            const size_t first = sub_first[it], cnt = sub_cnt[it];
             if (sh.shared) pack_shared(h_in(it));
             pack(first, cnt, h_in(it) + sh.shared);
             stamp("packed", it);

@@ -29,13 +29,11 @@ constexpr int ntt_fwd_prio(int logn) { return logn == 11 ? 0 : HX_FWD_PRIO; }
 
 using namespace hx;
 
-// per-lane twiddles of the persistent FP64 transforms requested ahead of their butterflies (ntt_core_f64.hpp WgNttF64 PRE / IPRE, as in
-// keyswitch_x.hip): round-6 experiment knobs
-#ifndef NTT_PRE
-#define NTT_PRE 0
-#endif
+// k_ntt_inv_p: the per-lane twiddle pairs of an inverse pass requested before its butterflies (ntt_core_f64.hpp inv_stages_f64_pre, as in
+// k_ksx_intt): +2.4 % inverse at batch 1024 (13.5 -> 13.85 M NTT/s, two rounds), +-0 at 4096. The forward counterpart (WgNttF64 PRE = 1 / 10 /
+// 11, the keyswitch's early twiddle requests) measured within noise either way and stays off (profiles/r06_ab_ntt_pre.txt).
 #ifndef NTT_IPRE
-#define NTT_IPRE 0
+#define NTT_IPRE 1
 #endif
 // (the kernels' SEMI parameter: strict tier with the semi-strict butterflies in the WAVE-UNIFORM passes, ntt_core_f64.hpp SEMIU)
 
@@ -103,6 +101,14 @@ __device__ __forceinline__ bool ntt_tables_ready(const NttPrep& pr, const double
 
 // Integer fallbacks of the fast-path kernels, kept out of line so that their register needs do not leak into the
 // FP64 code (inlined, the allocator spilled ~100 VGPRs on the fast path).
+// Round 6 measured the two alternatives the review asked for (profiles/r06_ab_ntt_redo.txt, tools/experiments/
+// r06_ntt_redo_all_and_address_spaces.patch): (a) the fallback of EVERY N = 16384 persistent kernel in a k_ntt_redo_* launch of its own -- the
+// fast kernels then need 92-94 VGPRs and no scratch at all (with the call: 128 VGPRs, 140-220 B of scratch around it) -- runs forward 13.2-13.3 /
+// 15.0-15.1 M NTT/s at batch 1024 / 4096 and inverse 13.4-13.5 / 14.2 M against 13.35-13.4 / 15.2 M and 13.3-13.4 / 14.25 M with the call: the
+// cleaner kernel gains what the extra (nearly always empty) dispatch costs, and a batch under tables that are not Shoup tables would run
+// on 32 workgroups instead of the full grid -- the call stays; (b) address-space-qualified pointer parameters for these functions (their
+// generic pointers make every access a FLAT operation, 70-145 per call) DOUBLE the caller's spills (k_ntt_inv_p: 24 -> 54 VGPRs, four of
+// them inside the loop) and cost the inverse 3-9 % -- the generic pointers stay.
 template <int LOGN, int LOGE>
 __device__ __attribute__((noinline)) void slow_fwd(u64* px, u64* lds, const u64* roots, const u64* precon, u64 q) {
     using G = Geom<LOGN, LOGE>;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY, (Geom<LOGN, LOGE>::P >= 3 ? NTT_PRE : 0), (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
