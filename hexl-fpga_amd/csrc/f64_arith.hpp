@@ -291,4 +291,157 @@ static_assert(LAZY_SKIP_MAX_RATIO < 1.0 / tier_a(3) && 2.0 * inv_chain(LAZY_SKIP
               "inverse chain from un-centred inputs");
 }  // namespace bounds
 
+// ---- "X schedules" (round 6): range-reduce only the ADDED operand, only where the chain needs it -------------------------------------
+// In a forward butterfly X' = X + t, Y' = X - t, t = mul_mod(Y, w), the multiplied operand never needs a range reduction: |t| <= (0.5 +
+// 1.5 a |Y| / p) p for any |Y| < 2^53 (a = p 2^-53). Only X carries the bound forward. The periodic schedules above reduce BOTH outputs
+// of every butterfly after each period-th stage (6 instructions per butterfly); an X schedule instead reduces, in front of chosen stages,
+// just the X input (3 instructions):
+//     N  nothing                          |x| <= c p  ->  (1 + 1.5 a) c + 0.5
+//     X  X = reduce(X) before the stage               ->  (0.5 + 0.5) + 1.5 a c
+//     F  X and Y reduced before the stage             ->  (0.5 + 0.5) + 0.75 a
+// and every value must stay below 2^53 = p / a. tools/gen_xsched.py brute-forces the cheapest schedule per tier (at the tier's largest
+// modulus), input bound (shift 0: centred values or the SKIP mod-down's 0.5 rho p, c0 = 0.625; shift 1: canonical residues of a neighbouring
+// modulus, c0 = rho = 1.25), stage count, and consumer (down = 1: the mod-down epilogue subtracts the un-reduced tail from an un-reduced
+// accumulator, tail <= 1 / a - MAC_FOLD_ACC; down = 0: mac_fold or a final range reduction, which only need the tail below 2^53).
+// N = 16384, top tier: 18 instead of 24 instructions per butterfly column for a mod-up transform, 21 instead of 24 for a mod-down one
+// (-2.5 % of a keyswitch's instructions); period-6 tier 6 instead of 12; period-12 tier 3 instead of 6.
+// Encoding: two bits per global stage s (1-based) at bits 2 (s - 1): 0 N, 1 X, 2 F; bit 31 = entry present. The table is DATA: xsched_ok
+// below replays the recurrence for every entry under static_assert, and tests/cpp/f64_selftest.cpp replays whole transforms on these
+// schedules against exact integers at the tier tops.
+struct XSchedEntry { int period, shift, down, stages; unsigned mask; };
+constexpr XSchedEntry XSCHED_TABLE[] = {
+    { 3, 0, 0,  8, 0x80001110u},   // NNXNXNXN          9 (periodic: 12)  3.701 of 3.969
+    { 3, 0, 0,  9, 0x80004440u},   // NNNXNXNXN         9 (periodic: 12)  3.898 of 3.969
+    { 3, 0, 0, 10, 0x80011140u},   // NNNXXNXNXN       12 (periodic: 18)  3.773 of 3.969
+    { 3, 0, 0, 11, 0x80044440u},   // NNNXNXNXNXN      12 (periodic: 18)  3.908 of 3.969
+    { 3, 0, 0, 12, 0x80111140u},   // NNNXXNXNXNXN     15 (periodic: 18)  3.809 of 3.969
+    { 3, 0, 0, 13, 0x80444440u},   // NNNXNXNXNXNXN    15 (periodic: 24)  3.913 of 3.969
+    { 3, 0, 0, 14, 0x81111440u},   // NNNXNXXNXNXNXN   18 (periodic: 24)  3.843 of 3.969
+    { 3, 0, 0, 15, 0x84444440u},   // NNNXNXNXNXNXNXN  18 (periodic: 24)  3.916 of 3.969
+    { 3, 0, 1,  8, 0x80004510u},   // NNXNXXNX         12 (periodic: 12)  3.115 of 3.969
+    { 3, 0, 1,  9, 0x80011440u},   // NNNXNXXNX        12 (periodic: 12)  3.843 of 3.969
+    { 3, 0, 1, 10, 0x80045110u},   // NNXNXNXXNX       15 (periodic: 18)  3.500 of 3.969
+    { 3, 0, 1, 11, 0x80114440u},   // NNNXNXNXXNX      15 (periodic: 18)  3.879 of 3.969
+    { 3, 0, 1, 12, 0x80451110u},   // NNXNXNXNXXNX     18 (periodic: 18)  3.701 of 3.969
+    { 3, 0, 1, 13, 0x81144440u},   // NNNXNXNXNXXNX    18 (periodic: 24)  3.898 of 3.969
+    { 3, 0, 1, 14, 0x84511140u},   // NNNXXNXNXNXXNX   21 (periodic: 24)  3.773 of 3.969
+    { 3, 0, 1, 15, 0x91444440u},   // NNNXNXNXNXNXXNX  21 (periodic: 24)  3.908 of 3.969
+    { 3, 1, 0,  8, 0x80001110u},   // NNXNXNXN          9 (periodic: 12)  3.868 of 3.969
+    { 3, 1, 0,  9, 0x80004450u},   // NNXXNXNXN        12 (periodic: 18)  3.697 of 3.969
+    { 3, 1, 0, 10, 0x80011110u},   // NNXNXNXNXN       12 (periodic: 18)  3.892 of 3.969
+    { 3, 1, 0, 11, 0x80044510u},   // NNXNXXNXNXN      15 (periodic: 18)  3.733 of 3.969
+    { 3, 1, 0, 12, 0x80111110u},   // NNXNXNXNXNXN     15 (periodic: 24)  3.905 of 3.969
+    { 3, 1, 0, 13, 0x80444510u},   // NNXNXXNXNXNXN    18 (periodic: 24)  3.808 of 3.969
+    { 3, 1, 0, 14, 0x81111110u},   // NNXNXNXNXNXNXN   18 (periodic: 24)  3.911 of 3.969
+    { 3, 1, 0, 15, 0x84445110u},   // NNXNXNXXNXNXNXN  21 (periodic: 30)  3.822 of 3.969
+    { 3, 1, 1,  8, 0x80004510u},   // NNXNXXNX         12 (periodic: 12)  3.733 of 3.969
+    { 3, 1, 1,  9, 0x80011444u},   // NXNXNXXNX        15 (periodic: 18)  3.459 of 3.969
+    { 3, 1, 1, 10, 0x80045110u},   // NNXNXNXXNX       15 (periodic: 18)  3.822 of 3.969
+    { 3, 1, 1, 11, 0x80114450u},   // NNXXNXNXXNX      18 (periodic: 18)  3.562 of 3.969
+    { 3, 1, 1, 12, 0x80451110u},   // NNXNXNXNXXNX     18 (periodic: 24)  3.868 of 3.969
+    { 3, 1, 1, 13, 0x81144450u},   // NNXXNXNXNXXNX    21 (periodic: 24)  3.697 of 3.969
+    { 3, 1, 1, 14, 0x84511110u},   // NNXNXNXNXNXXNX   21 (periodic: 24)  3.892 of 3.969
+    { 3, 1, 1, 15, 0x91444510u},   // NNXNXXNXNXNXXNX  24 (periodic: 30)  3.733 of 3.969
+    { 6, 0, 0,  8, 0x80000100u},   // NNNNXNNN          3 (periodic:  6)  4.691 of 8.000
+    { 6, 0, 0,  9, 0x80000400u},   // NNNNNXNNN         3 (periodic:  6)  5.106 of 8.000
+    { 6, 0, 0, 10, 0x80000400u},   // NNNNNXNNNN        3 (periodic:  6)  6.529 of 8.000
+    { 6, 0, 0, 11, 0x80001000u},   // NNNNNNXNNNN       3 (periodic:  6)  7.072 of 8.000
+    { 6, 0, 0, 12, 0x80010100u},   // NNNNXNNNXNNN      6 (periodic:  6)  4.946 of 8.000
+    { 6, 0, 0, 13, 0x80040400u},   // NNNNNXNNNXNNN     6 (periodic: 12)  5.106 of 8.000
+    { 6, 0, 0, 14, 0x80040400u},   // NNNNNXNNNXNNNN    6 (periodic: 12)  6.517 of 8.000
+    { 6, 0, 0, 15, 0x80101000u},   // NNNNNNXNNNXNNNN   6 (periodic: 12)  6.688 of 8.000
+    { 6, 0, 1,  8, 0x80000100u},   // NNNNXNNN          3 (periodic:  6)  4.691 of 8.000
+    { 6, 0, 1,  9, 0x80000400u},   // NNNNNXNNN         3 (periodic:  6)  5.106 of 8.000
+    { 6, 0, 1, 10, 0x80001000u},   // NNNNNNXNNN        3 (periodic:  6)  6.564 of 8.000
+    { 6, 0, 1, 11, 0x80004100u},   // NNNNXNNXNNN       6 (periodic:  6)  4.582 of 8.000
+    { 6, 0, 1, 12, 0x80010100u},   // NNNNXNNNXNNN      6 (periodic:  6)  4.946 of 8.000
+    { 6, 0, 1, 13, 0x80040400u},   // NNNNNXNNNXNNN     6 (periodic: 12)  5.106 of 8.000
+    { 6, 0, 1, 14, 0x80100400u},   // NNNNNXNNNNXNNN    6 (periodic: 12)  6.529 of 8.000
+    { 6, 0, 1, 15, 0x80401000u},   // NNNNNNXNNNNXNNN   6 (periodic: 12)  7.072 of 8.000
+    { 6, 1, 0,  8, 0x80000100u},   // NNNNXNNN          3 (periodic:  6)  5.122 of 8.000
+    { 6, 1, 0,  9, 0x80000100u},   // NNNNXNNNN         3 (periodic:  6)  6.534 of 8.000
+    { 6, 1, 0, 10, 0x80000400u},   // NNNNNXNNNN        3 (periodic:  6)  7.079 of 8.000
+    { 6, 1, 0, 11, 0x80004040u},   // NNNXNNNXNNN       6 (periodic:  6)  4.948 of 8.000
+    { 6, 1, 0, 12, 0x80010100u},   // NNNNXNNNXNNN      6 (periodic: 12)  5.122 of 8.000
+    { 6, 1, 0, 13, 0x80010100u},   // NNNNXNNNXNNNN     6 (periodic: 12)  6.519 of 8.000
+    { 6, 1, 0, 14, 0x80040400u},   // NNNNNXNNNXNNNN    6 (periodic: 12)  6.690 of 8.000
+    { 6, 1, 0, 15, 0x80100400u},   // NNNNNXNNNNXNNNN   6 (periodic: 12)  7.264 of 8.000
+    { 6, 1, 1,  8, 0x80000100u},   // NNNNXNNN          3 (periodic:  6)  5.122 of 8.000
+    { 6, 1, 1,  9, 0x80000400u},   // NNNNNXNNN         3 (periodic:  6)  6.582 of 8.000
+    { 6, 1, 1, 10, 0x80001040u},   // NNNXNNXNNN        6 (periodic:  6)  4.583 of 8.000
+    { 6, 1, 1, 11, 0x80004040u},   // NNNXNNNXNNN       6 (periodic:  6)  4.948 of 8.000
+    { 6, 1, 1, 12, 0x80010100u},   // NNNNXNNNXNNN      6 (periodic: 12)  5.122 of 8.000
+    { 6, 1, 1, 13, 0x80040100u},   // NNNNXNNNNXNNN     6 (periodic: 12)  6.534 of 8.000
+    { 6, 1, 1, 14, 0x80100400u},   // NNNNNXNNNNXNNN    6 (periodic: 12)  7.079 of 8.000
+    { 6, 1, 1, 15, 0x80404040u},   // NNNXNNNXNNNXNNN   9 (periodic: 12)  5.027 of 8.000
+    {12, 0, 0,  8, 0x80000000u},   // NNNNNNNN          0 (periodic:  0)  6.870 of 16.000
+    {12, 0, 0,  9, 0x80000000u},   // NNNNNNNNN         0 (periodic:  0)  8.014 of 16.000
+    {12, 0, 0, 10, 0x80000000u},   // NNNNNNNNNN        0 (periodic:  0)  9.265 of 16.000
+    {12, 0, 0, 11, 0x80000000u},   // NNNNNNNNNNN       0 (periodic:  0)  10.634 of 16.000
+    {12, 0, 0, 12, 0x80000000u},   // NNNNNNNNNNNN      0 (periodic:  0)  12.131 of 16.000
+    {12, 0, 0, 13, 0x80000000u},   // NNNNNNNNNNNNN     0 (periodic:  6)  13.768 of 16.000
+    {12, 0, 0, 14, 0x80000000u},   // NNNNNNNNNNNNNN    0 (periodic:  6)  15.559 of 16.000
+    {12, 0, 0, 15, 0x80010000u},   // NNNNNNNNXNNNNNN   3 (periodic:  6)  6.870 of 16.000
+    {12, 0, 1,  8, 0x80000000u},   // NNNNNNNN          0 (periodic:  0)  6.870 of 16.000
+    {12, 0, 1,  9, 0x80000000u},   // NNNNNNNNN         0 (periodic:  0)  8.014 of 16.000
+    {12, 0, 1, 10, 0x80000000u},   // NNNNNNNNNN        0 (periodic:  0)  9.265 of 16.000
+    {12, 0, 1, 11, 0x80000000u},   // NNNNNNNNNNN       0 (periodic:  0)  10.634 of 16.000
+    {12, 0, 1, 12, 0x80000000u},   // NNNNNNNNNNNN      0 (periodic:  0)  12.131 of 16.000
+    {12, 0, 1, 13, 0x80000000u},   // NNNNNNNNNNNNN     0 (periodic:  6)  13.768 of 16.000
+    {12, 0, 1, 14, 0x80004000u},   // NNNNNNNXNNNNNN    3 (periodic:  6)  6.444 of 16.000
+    {12, 0, 1, 15, 0x80010000u},   // NNNNNNNNXNNNNNN   3 (periodic:  6)  6.870 of 16.000
+    {12, 1, 0,  8, 0x80000000u},   // NNNNNNNN          0 (periodic:  0)  8.150 of 16.000
+    {12, 1, 0,  9, 0x80000000u},   // NNNNNNNNN         0 (periodic:  0)  9.414 of 16.000
+    {12, 1, 0, 10, 0x80000000u},   // NNNNNNNNNN        0 (periodic:  0)  10.796 of 16.000
+    {12, 1, 0, 11, 0x80000000u},   // NNNNNNNNNNN       0 (periodic:  0)  12.309 of 16.000
+    {12, 1, 0, 12, 0x80000000u},   // NNNNNNNNNNNN      0 (periodic:  6)  13.962 of 16.000
+    {12, 1, 0, 13, 0x80000000u},   // NNNNNNNNNNNNN     0 (periodic:  6)  15.771 of 16.000
+    {12, 1, 0, 14, 0x80004000u},   // NNNNNNNXNNNNNN    3 (periodic:  6)  6.994 of 16.000
+    {12, 1, 0, 15, 0x80004000u},   // NNNNNNNXNNNNNNN   3 (periodic:  6)  7.754 of 16.000
+    {12, 1, 1,  8, 0x80000000u},   // NNNNNNNN          0 (periodic:  0)  8.150 of 16.000
+    {12, 1, 1,  9, 0x80000000u},   // NNNNNNNNN         0 (periodic:  0)  9.414 of 16.000
+    {12, 1, 1, 10, 0x80000000u},   // NNNNNNNNNN        0 (periodic:  0)  10.796 of 16.000
+    {12, 1, 1, 11, 0x80000000u},   // NNNNNNNNNNN       0 (periodic:  0)  12.309 of 16.000
+    {12, 1, 1, 12, 0x80000000u},   // NNNNNNNNNNNN      0 (periodic:  6)  13.962 of 16.000
+    {12, 1, 1, 13, 0x80001000u},   // NNNNNNXNNNNNN     3 (periodic:  6)  6.462 of 16.000
+    {12, 1, 1, 14, 0x80004000u},   // NNNNNNNXNNNNNN    3 (periodic:  6)  6.994 of 16.000
+    {12, 1, 1, 15, 0x80004000u},   // NNNNNNNXNNNNNNN   3 (periodic:  6)  7.754 of 16.000
+};
+constexpr int XSCHED_ENTRIES = sizeof(XSCHED_TABLE) / sizeof(XSCHED_TABLE[0]);
+constexpr unsigned XSCHED_PRESENT = 0x80000000u;
+// the schedule for a `stages`-stage forward transform (0 = none in the table: callers fall back to the periodic schedule)
+HX_HD constexpr unsigned xsched_mask(int period, int shift, bool down, int stages) {
+    for (int i = 0; i < XSCHED_ENTRIES; ++i)
+        if (XSCHED_TABLE[i].period == period && XSCHED_TABLE[i].shift == shift && XSCHED_TABLE[i].down == (down ? 1 : 0) &&
+            XSCHED_TABLE[i].stages == stages) return XSCHED_TABLE[i].mask;
+    return 0u;
+}
+HX_HD constexpr int xsched_op(unsigned mask, int s) { return int((mask >> (2 * (s - 1))) & 3u); }     // s = global stage, 1-based (s <= 15)
+namespace bounds {
+constexpr double xsched_c0(int shift) { return shift ? LAZY_SKIP_MAX_RATIO : 0.5 * LAZY_SKIP_MAX_RATIO; }
+constexpr bool xsched_ok(const XSchedEntry& e) {
+    if (!(e.mask & XSCHED_PRESENT) || e.stages > 15) return false;                // (15 stages x 2 bits + the present bit)
+    const double a = tier_a(e.period), limit = 1.0 / a, r = 0.5 + SLOP;
+    double c = xsched_c0(e.shift);
+    for (int s = 1; s <= e.stages; ++s) {
+        const int op = xsched_op(e.mask, s);
+        if (op == 0) c = (1.0 + 1.5 * a) * c + 0.5;
+        else if (op == 1) c = r + 0.5 + 1.5 * a * c;
+        else if (op == 2) c = r + 0.5 + 1.5 * a * r;
+        else return false;
+        if (!(c < limit)) return false;
+    }
+    if (e.down && !(MAC_FOLD_ACC + c < limit)) return false;
+    // mac_fold on the un-reduced tail: |x k| < 2^103 (|l| <= 2^49) with |k| <= p / 2
+    if (!(c * tier_top(e.period) * tier_top(e.period) * 0.5 < 10141204801825835211973625643008.0)) return false;
+    return true;
+}
+constexpr bool xsched_table_ok() {
+    for (int i = 0; i < XSCHED_ENTRIES; ++i)
+        if (!xsched_ok(XSCHED_TABLE[i])) return false;
+    return true;
+}
+static_assert(xsched_table_ok(), "an X schedule of XSCHED_TABLE passes 2^53 (or its tail does not fit under the mod-down epilogue): regenerate with tools/gen_xsched.py");
+}  // namespace bounds
+
 }  // namespace hxf

@@ -202,6 +202,12 @@ constexpr int KX_PF = KX_PF_DEPTH;
 #define KX_SEMI_UNI 1
 #endif
 #define KX_SEMIU_ON(LAZY) ((LAZY) == 0 && KX_SEMI_UNI != 0)
+// lazy kernels, N <= 16384: the forward transforms run the X schedules of f64_arith.hpp (range reduction of the added operand only, where the bound
+// chain needs it) instead of the periodic full reductions: 18 / 21 instead of 24 reduction instructions per butterfly column at N = 16384 in
+// the top tier (mod-up / mod-down), 2.5 % of a keyswitch's instructions. 0 = the periodic schedules (A/B: tools/build_variant.sh).
+#ifndef KX_XSCHED
+#define KX_XSCHED 1
+#endif
 // FOLD: the folded multiply-accumulate (f64_arith.hpp mac_fold; lazy tiers: accumulators <= 1.6p between rounds, strict tier <= 0.9p)
 // CSW: words between the two key components of a row (0: G::N; the N = 32768 kernels work on HALF rows of rows that are 2 G::N long)
 template <class G, bool FOLD = false, int CSW = 0>
@@ -384,7 +390,7 @@ template <int LOGN, int LOGE, int LAZY, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY)>;
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY), KX_XSCHED ? 0 : -1>;   // forward output -> mac_fold
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;
@@ -544,8 +550,8 @@ template <int LOGN, int LOGE, int LAZY, bool FUSED = false, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, 0, false, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY)>;               // mod-down transforms: centred input
-    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY)>;   // mod-up transforms (SKIP: canonical c_d as it is)
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, 0, false, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY), KX_XSCHED ? 1 : -1>;               // mod-down transforms: centred input, tail -> acc - w
+    using WU = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY), KX_XSCHED ? 0 : -1>;   // mod-up transforms (SKIP: canonical c_d as it is), tail -> mac_fold
     // lazy kernels: the d == i term and the accumulators go un-reduced into the folded multiply-accumulate (f64_arith.hpp mac_fold,
     // |acc| <= 1.6p between rounds). The strict kernels (moduli up to 2^52) fold theirs too (transform output |x| <= p/2 + 2,
     // accumulators <= 0.9p between terms) and reduce the accumulators once in front of the mod-down, whose epilogue needs them centred
@@ -673,11 +679,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_main
 // result need no exchange at all; only the coefficient-domain arrays (c_d, s') are read in full by both halves: + 1 load, a reduction and
 // 7 FP64 operations per coefficient and round. Same arithmetic as the monolithic transforms of the (b, d)-major kernels: bit-identical.
 constexpr int KSH_HB = 8;      // words of the other half requested at a time in ksh_combine
-template <class G, int LAZY, bool SKIP, int SHIFT>
+template <class G, int LAZY, bool SKIP, int SHIFT, unsigned XS = 0u>
 __device__ __forceinline__ void ksh_combine(double (&v)[G::E], const double* __restrict__ hi_row, int tid, const double* w, const Mod m, u32 h) {
     // forward global stage 1 of the 2^15-point transform (one twiddle: index 1), this workgroup keeps output half h
     const double W1 = ((ctw_t)w)[1];
-    constexpr bool red = LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, SHIFT);   // (the transform's own schedule)
+    // (the transform's own schedule; on an X schedule -- XS = the sub-transforms' mask -- stage 1 is never a reduction point)
+    constexpr bool red = XS ? false : (LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, SHIFT));
     // the other half's words, HB at a time: all sixteen in flight at once need 32 registers the accumulators do not leave
     constexpr int HB = KSH_HB;
 #pragma unroll
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(256) void k_ksh_finish(KsArgsX a, u32 rows) {
 template <int LAZY, bool SKIP>
 __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY)>;
+    using W = WgNttF64<14, 4, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY), KX_XSCHED ? 0 : -1>;
     constexpr u32 NF = 2 * G::N;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L, isp = a.K - 1;
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
             u32 tsp = isp * 4 * NF;
             asm volatile("" : "+s"(tsp));
             const double* ts = a.tables + tsp;
-            ksh_combine<G, LAZY, SKIP, (SKIP ? 1 : 0)>(v, a.c + (size_t(b) * L + it) * NF + G::N, tid, ts, msp.m, h);
+            ksh_combine<G, LAZY, SKIP, (SKIP ? 1 : 0), W::XS>(v, a.c + (size_t(b) * L + it) * NF + G::N, tid, ts, msp.m, h);
             const double* k0 = key_row<G>(a, it, L) + h * G::N;
             const u32 nd = it + 1 < L ? it + 1 : it;
             W::template forward<false, false>(v, ldsx, tid, ts, ts + NF, msp.m, typename W::NoHook(), typename W::NoHook(), h);
@@ -813,8 +820,8 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
 template <int LAZY, bool SKIP, bool FUSED = false>
 __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
     using G = Geom<14, 4>;
-    using W = WgNttF64<14, 4, LAZY, KX_PRE, 0, false, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY)>;                 // mod-down transforms: centred input
-    using WU = WgNttF64<14, 4, LAZY, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY)>;     // mod-up transforms
+    using W = WgNttF64<14, 4, LAZY, KX_PRE, 0, false, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY), KX_XSCHED ? 1 : -1>;                 // mod-down transforms: centred input
+    using WU = WgNttF64<14, 4, LAZY, KX_PRE, SKIP ? 1 : 0, false, HX_FWD_PRIO, 1, KX_SEMIU_ON(LAZY), KX_XSCHED ? 0 : -1>;     // mod-up transforms
     constexpr u32 NF = 2 * G::N;
     constexpr bool LAZYFOLD = LAZY != 0;
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
@@ -849,7 +856,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         u32 toff = i * 4 * NF;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        ksh_combine<G, LAZY, SKIP, (SKIP ? 1 : 0)>(v, round_src(it) + G::N, tid, tb, m, h);
+        ksh_combine<G, LAZY, SKIP, (SKIP ? 1 : 0), WU::XS>(v, round_src(it) + G::N, tid, tb, m, h);
         u32 nit = it + 1;
         if (nit == i) ++nit;
         const double* k0 = key_row<G>(a, it, i) + h * G::N;
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         u32 toff = i * 4 * NF;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L) + G::N, tid, tb, m, h);
+        ksh_combine<G, LAZY, SKIP, 0, W::XS>(v, round_src(L) + G::N, tid, tb, m, h);
         const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 0, SKIP, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
         else ksx_down_round<G, W, -1, SKIP, true>(v, acc0, a.result + o0, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_main(KsArgsX a) {
         u32 toff = i * 4 * NF;
         asm volatile("" : "+s"(toff));
         const double* tb = a.tables + toff;
-        ksh_combine<G, LAZY, SKIP, 0>(v, round_src(L + 1) + G::N, tid, tb, m, h);
+        ksh_combine<G, LAZY, SKIP, 0, W::XS>(v, round_src(L + 1) + G::N, tid, tb, m, h);
         const size_t o0 = ((size_t(b) * 2 + 0) * L + i) * NF + h * G::N, o1 = ((size_t(b) * 2 + 1) * L + i) * NF + h * G::N;
         if constexpr (FUSED) ksx_down_round<G, W, 1, SKIP, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, a.mul_a + o0, a.mul_a + o1, a.mul_b + o0, a.mul_b + o1, h);
         else ksx_down_round<G, W, -1, SKIP, true>(v, acc1, a.result + o1, ldsx, tid, tb, md, bad, nullptr, nullptr, nullptr, nullptr, h);

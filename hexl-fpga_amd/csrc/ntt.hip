@@ -35,6 +35,11 @@ using namespace hx;
 #ifndef NTT_IPRE
 #define NTT_IPRE 1
 #endif
+// lazy tiers, N <= 16384: the forward transform on the X schedule of f64_arith.hpp (the added operand range-reduced where the bound chain needs
+// it: 18 + the final 6 instead of 30 reduction instructions per butterfly column in the top tier). 0 = the periodic schedule.
+#ifndef NTT_XSCHED
+#define NTT_XSCHED 1
+#endif
 // (the kernels' SEMI parameter: strict tier with the semi-strict butterflies in the WAVE-UNIFORM passes, ntt_core_f64.hpp SEMIU)
 
 // ---------------------------------------------------------------------------------------------
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_x(u64* __restric
     // The FP64 transform runs unconditionally; whether its preconditions held for this polynomial is voted on
     // afterwards (a barrier at the very end costs nothing, one before the transform would put all 16 waves back
     // in lockstep). The input is still intact in memory for the integer fallback.
-    WgNttF64<LOGN, LOGE, LAZY, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+    WgNttF64<LOGN, LOGE, LAZY, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI, NTT_XSCHED ? 0 : -1>::template forward<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
     const bool slow = __syncthreads_or(out_of_range);
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_fwd_p(u64* __restric
         const u64* pnx = x + size_t(pn) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxA(r, 0))[u32(tid)];
-        WgNttF64<LOGN, LOGE, LAZY, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
+        WgNttF64<LOGN, LOGE, LAZY, 0, (LAZY != 0 ? 1 : 0), false, ntt_fwd_prio(LOGN), 0, SEMI, NTT_XSCHED ? 0 : -1>::template forward<false>(f, reinterpret_cast<double*>(lds), tid, w, wp, m);
         const bool slow = vote.result(tid);                                      // see k_ntt_fwd_x, RangeVote
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxB(r, tid); });
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(1024) void k_ntt_fwd_h(u64* __restrict__ x, const u
                                                     u64 q, NttPrep prep, u32 batch, NttHint hint) {
     using G = Geom<14, 4>;
     constexpr int FS = LAZY != 0 ? 1 : 0;
-    using W = WgNttF64<14, 4, LAZY, 0, FS, false, ntt_fwd_prio(14), 1, SEMI>;
+    using W = WgNttF64<14, 4, LAZY, 0, FS, false, ntt_fwd_prio(14), 1, SEMI, NTT_XSCHED ? 0 : -1>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u64 limit = fast_path_limit<LAZY>(q, true);
     const Mod m{(double)q, 1.0 / (double)q};
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_ntt_fwd_h(u64* __restrict__ x, const u
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
     const double W1 = ((ctw_t)w)[1];                                            // global stage 1: one twiddle
-    constexpr bool red = LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, FS);
+    constexpr bool red = W::XS ? false : (LAZY == 0 || hxf::lazy_fwd_reduce_after(1, 15, LAZY ? LAZY : 3, FS));   // (X schedules: stage 1 is an N stage)
 #pragma unroll 1
     for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
         int tid = threadIdx.x;

@@ -26,9 +26,13 @@ typedef const __attribute__((address_space(4))) double* ctw_t;
 // drops it and hands over three un-reduced stages, 3.45p, instead (f64_arith.hpp)
 // SEMI (strict kernels only, LAZY == 0): the semi-strict schedule of f64_arith.hpp ct_bfly_semi -- Shoup-form products (the w/p table
 // IS read here) and outputs reduced only where the next stage adds them; the last stage of the call reduces everything.
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int SHIFT = 0, int NORED = 0, bool SEMI = false>
+// XS != 0 (round 6, lazy kernels): an X schedule of f64_arith.hpp (xsched_mask) replaces the periodic one -- per global stage nothing, the
+// added operand or both operands are range-reduced IN FRONT of the butterfly; SHIFT and NORED are then unused (the mask was chosen for the
+// input bound and the consumer), LOGN != 0 still asks for the full reduction after the last stage.
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, bool UNI = false, int SHIFT = 0, int NORED = 0, bool SEMI = false, unsigned XS = 0u>
 __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const double* __restrict__ w,
                                                const double* __restrict__ wp, const Mod m) {
+    static_assert(XS == 0u || (LAZY > 0 && !SEMI), "X schedules: lazy kernels");
     if constexpr (SEMI) {
         static_assert(LAZY == 0, "semi-strict schedule: strict kernels");
 #pragma unroll
@@ -52,13 +56,17 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const u32 base = (1u << (S0 - 1 + u)) + (G << u);
-        const bool red = !LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED);
+        const bool red = XS ? (LOGN != 0 && S0 + u == LOGN)
+                            : (!LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED));
+        const int xop = XS ? hxf::xsched_op(XS, S0 + u) : 0;
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = UNI ? ((ctw_t)w)[base + j] : w[base + j];          // forward butterflies need no w/p table
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
+                if (xop >= 1) v[a0] = hxf::reduce(v[a0], m);
+                if (xop == 2) v[a0 + (1 << (K - 1 - u))] = hxf::reduce(v[a0 + (1 << (K - 1 - u))], m);
                 if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
                 else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
             }
@@ -67,17 +75,21 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[E], u32 G, const doub
 }
 
 // the same K stages with their 2^K - 1 twiddles already in registers (tw[(1 << u) - 1 + j] = stage u, sub-block j)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0, int NORED = 0>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0, int NORED = 0, unsigned XS = 0u>
 __device__ __forceinline__ void fwd_stages_f64_tw(double (&v)[E], const double (&tw)[(1 << K) - 1], const Mod m) {
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-        const bool red = !LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED);
+        const bool red = XS ? (LOGN != 0 && S0 + u == LOGN)
+                            : (!LAZY || (hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT) && (S0 + u) != NORED));
+        const int xop = XS ? hxf::xsched_op(XS, S0 + u) : 0;
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = tw[(1 << u) - 1 + j];
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
+                if (xop >= 1) v[a0] = hxf::reduce(v[a0], m);
+                if (xop == 2) v[a0 + (1 << (K - 1 - u))] = hxf::reduce(v[a0 + (1 << (K - 1 - u))], m);
                 if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
                 else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
             }
@@ -89,7 +101,7 @@ __device__ __forceinline__ void fwd_stages_f64_tw(double (&v)[E], const double (
 // where the compiler puts them: one exposed wait instead of K - 1 at the price of 2^K - 2 registers. (Requesting stage
 // u + 2 ahead of the butterflies of stage u as well -- two stages' twiddles live -- spilled 24-36 registers in the
 // keyswitch kernels: 179 k against 200 k keyswitch/s.)
-template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0>
+template <int E, int OFF, int K, int S0, int LOGN = 0, int LAZY = 0, int SHIFT = 0, unsigned XS = 0u>
 __device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, const double* __restrict__ w, const Mod m) {
     double tw[(1 << (K - 1)) - 1];
 #pragma unroll
@@ -99,13 +111,16 @@ __device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, cons
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-        const bool red = !LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT);
+        const bool red = XS ? (LOGN != 0 && S0 + u == LOGN) : (!LAZY || hxf::lazy_fwd_reduce_after(S0 + u, LOGN, LAZY ? LAZY : 3, SHIFT));
+        const int xop = XS ? hxf::xsched_op(XS, S0 + u) : 0;
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const double W = u + 1 < K ? tw[(1 << u) - 1 + j] : w[(1u << (S0 - 1 + u)) + (G << u) + j];
 #pragma unroll
             for (int c = 0; c < (1 << (K - 1 - u)); ++c) {
                 const int a0 = OFF + (j << (K - u)) + c;
+                if (xop >= 1) v[a0] = hxf::reduce(v[a0], m);
+                if (xop == 2) v[a0 + (1 << (K - 1 - u))] = hxf::reduce(v[a0 + (1 << (K - 1 - u))], m);
                 if (red) hxf::ct_bfly(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
                 else     hxf::ct_bfly_lazy(v[a0], v[a0 + (1 << (K - 1 - u))], W, m);
             }
@@ -257,12 +272,19 @@ __device__ __forceinline__ void hx_inv_prio() {
 // no vector loads, no registers and does not disturb the per-lane passes' early twiddle requests (PRE), which is what made the all-passes
 // variant of round 4 lose. The schedule is pass-local (f64_arith.hpp ct_bfly_semi: a pass starts from reduced values and its last stage
 // reduces everything), so strict and semi-strict passes mix freely.
-template <int LOGN, int LOGE, int LAZY = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, int TOP = 0, bool SEMIU = false>
+// XSD (round 6, lazy kernels): -1 = the periodic reduction schedule; 0 / 1 = the X schedule of f64_arith.hpp for this tier, input kind
+// (FSHIFT) and transform size, chosen for a consumer that takes any tail below 2^53 (mac_fold, or FINAL's range reduction: 0) or for the
+// mod-down epilogue (un-reduced accumulator minus the tail: 1). Strict kernels keep their schedules.
+template <int LOGN, int LOGE, int LAZY = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, int TOP = 0, bool SEMIU = false, int XSD = -1>
 struct WgNttF64 {
     static_assert(!SEMIU || LAZY == 0, "semi-strict uniform passes: strict kernels");
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
     static constexpr int FLOGN = LOGN + TOP;                      // log2 of the full transform
+    static constexpr unsigned XS = (XSD >= 0 && LAZY > 0) ? hxf::xsched_mask(LAZY, FSHIFT, XSD == 1, FLOGN) : 0u;
+    static_assert(XSD < 0 || LAZY <= 0 || XS != 0u, "no X schedule in XSCHED_TABLE for this tier / input / size");
+    // (TOP > 0: the caller's outer stages follow the same mask -- keyswitch_x.hip ksh_combine, ntt.hip k_ntt_fwd_h: stage 1 is an N stage in every 15-stage schedule)
+    static_assert(TOP == 0 || XS == 0u || (TOP == 1 && hxf::xsched_op(XS, 1) == 0), "the outer stage of a split transform must be an N stage of its X schedule");
     // group index of the full transform for a local one at the pass whose first LOCAL stage is S0L (forward) ...
     template <int S0L>
     __device__ static __forceinline__ u32 gfwd(u32 top, u32 Gl) { if constexpr (TOP > 0) return (top << (S0L - 1)) | Gl; else return Gl; }
@@ -289,9 +311,9 @@ struct WgNttF64 {
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gl = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             const u32 Gp = gfwd<PASS * LOGE + 1>(top, Gl);
-            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, FSHIFT>(v, Gp, w, m);
+            if constexpr (PRE >= 10 && !(PASS == 0 || LO >= 6)) fwd_stages_f64_ahead<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, FSHIFT, XS>(v, Gp, w, m);
             else fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1 + TOP, FLOGN, LAZY, (PASS == 0 || LO >= 6), FSHIFT, 0,
-                                (SEMIU && (PASS == 0 || LO >= 6))>(v, Gp, w, wp, m);
+                                (SEMIU && (PASS == 0 || LO >= 6)), XS>(v, Gp, w, wp, m);
             constexpr bool LEAD = !(FRESH && PASS == 0);
             if constexpr (PRE > 0 && PASS + 1 == G::P - 1 && PASS > 0) {
                 constexpr int NT = (1 << G::KL) - 1, S0L = (G::P - 1) * LOGE + 1;
@@ -329,7 +351,7 @@ struct WgNttF64 {
             const u32 Gbits = gfwd<(G::P - 1) * LOGE + 1>(top, u32(G::grpB(GRP, tid)));
             // LOGN = 0 tells the stage loop that no stage is the last one
             fwd_stages_f64<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, false, FSHIFT,
-                           (!FINAL && FSHIFT != 0) ? FLOGN : 0>(v, Gbits, w, wp, m);
+                           (!FINAL && FSHIFT != 0) ? FLOGN : 0, false, XS>(v, Gbits, w, wp, m);
             fwd_last<GRP + 1, FINAL>(v, tid, w, wp, m, top);
         }
     }
@@ -337,7 +359,7 @@ struct WgNttF64 {
     __device__ static __forceinline__ void fwd_last_tw(double (&v)[E], const double (&tl)[G::NG][(1 << G::KL) - 1], const Mod m) {
         if constexpr (GRP < G::NG) {
             fwd_stages_f64_tw<E, GRP * (1 << G::KL), G::KL, (G::P - 1) * LOGE + 1 + TOP, FINAL ? FLOGN : 0, LAZY, FSHIFT,
-                              (!FINAL && FSHIFT != 0) ? FLOGN : 0>(v, tl[GRP], m);
+                              (!FINAL && FSHIFT != 0) ? FLOGN : 0, XS>(v, tl[GRP], m);
             fwd_last_tw<GRP + 1, FINAL>(v, tl, m);
         }
     }
@@ -357,7 +379,7 @@ struct WgNttF64 {
             constexpr int LO = LOGN - (PASS + 1) * LOGE;
             // LO >= 6: every lane of a wave shares the group index -> scalar twiddle loads
             const u32 Gp = (PASS == 0) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
-            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, false, FSHIFT>(v, Gp, w, wp, m);
+            fwd_stages_f64<E, 0, LOGE, PASS * LOGE + 1, LOGN, LAZY, false, FSHIFT, 0, false, XS>(v, Gp, w, wp, m);
             if constexpr (PASS + 1 < G::P - 1) {
                 constexpr int LO2 = LO - LOGE;
                 redeal_f64<G>(v, lds, tid, [](int r, int t) { return G::template idxF<LO>(r, t); },

@@ -338,6 +338,75 @@ static void test_round4(uint64_t n, uint64_t p, int period, double rho, bool adv
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(hxf::reduce(u[i], m), m)) == ref[i], "centred s' fwd n=%lu p=%lu i=%lu", n, p, i);
 }
 
+// ---- round 6: the X schedules (f64_arith.hpp XSCHED_TABLE; ntt_core_f64.hpp fwd_stages_f64<..., XS>) ------------------------------------
+// A forward transform that range-reduces only the added operand, in front of the stages the table names; inputs as the kernels feed them
+// (shift 1: canonical residues of a neighbouring modulus, [0, rho p); shift 0: centred values up to 0.5 rho p), no reduction after the last
+// stage, followed by the consumer the schedule was chosen for: mac_fold at |acc| = 1.6p (down = 0) or the mod-down epilogue
+// mul_shoup(acc - w) at |acc| = 1.7p (down = 1), signs chosen to push outwards.
+static double g_xs_max = 0, g_xs_tail = 0;
+static void test_xsched(uint64_t n, uint64_t p, int period, int shift, bool down, double rho, bool adversarial) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    int logn = 0; while ((1ull << logn) < n) ++logn;
+    const unsigned mask = hxf::xsched_mask(period, shift, down, logn);
+    CHECK(mask != 0u, "no X schedule for period %d shift %d down %d stages %d", period, shift, (int)down, logn);
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t* roots = blk.data() + 2 * n;
+    auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+    auto trackx = [&](double x) { const double a = x < 0 ? -x : x; if (a > g_xs_max) g_xs_max = a; };
+    const uint64_t top = (uint64_t)(rho * (double)p) - 1;
+    std::vector<uint64_t> ref(n);
+    std::vector<double> u(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        int64_t y;
+        if (shift) y = (int64_t)(adversarial ? top - (i & 3) : rnd() % (top + 1));
+        else y = adversarial ? ((i & 1) ? 1 : -1) * (int64_t)(top / 2) : (int64_t)(rnd() % (top + 1)) - (int64_t)(top / 2);
+        u[i] = (double)y;
+        ref[i] = (uint64_t)centred((i128)y, (int64_t)p);
+        if ((int64_t)ref[i] < 0) ref[i] += p;
+    }
+    orc_ks_ntt(ref.data(), n, p, roots);
+    int s = 1;
+    for (uint64_t mm = 1, t = n >> 1; mm < n; mm <<= 1, t >>= 1, ++s) {
+        const int op = hxf::xsched_op(mask, s);
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(roots[mm + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                if (op >= 1) u[j] = hxf::reduce(u[j], m);
+                if (op == 2) u[j + t] = hxf::reduce(u[j + t], m);
+                hxf::ct_bfly_lazy(u[j], u[j + t], w, m);
+                trackx(u[j]); trackx(u[j + t]);
+            }
+        }
+    }
+    std::vector<uint64_t> key(n);
+    orc_fill_splitmix(key.data(), n, p ^ 0x6666, p);
+    for (uint64_t i = 0; i < n; ++i) {
+        const double au = u[i] < 0 ? -u[i] : u[i];
+        if (au / (double)p > g_xs_tail) g_xs_tail = au / (double)p;
+        CHECK(u[i] == (double)(int64_t)u[i] && hxf::from_f64(hxf::lift(hxf::reduce(u[i], m), m)) == ref[i], "X schedule fwd n=%lu p=%lu (period %d shift %d down %d) i=%lu",
+              n, p, period, shift, (int)down, i);
+        if (!down) {
+            const uint64_t kv = adversarial ? ((i & 1) ? p / 2 : p / 2 + 1) : key[i];
+            const double kc = centre(kv);
+            const double acc0 = ((u[i] < 0) != (kc < 0) ? -1.0 : 1.0) * (double)(uint64_t)(1.6 * (double)p);
+            const double acc = hxf::mac_fold(acc0, u[i], kc, m);
+            trackx(acc);
+            const i128 exact = (i128)(int64_t)acc0 + (i128)(int64_t)u[i] * (int64_t)kc;
+            CHECK(acc == (double)(int64_t)acc && centred(exact - (int64_t)acc, (int64_t)p) == 0 && (acc < 0 ? -acc : acc) <= 1.7 * (double)p,
+                  "mac_fold on an X-schedule tail n=%lu p=%lu i=%lu acc=%.0f", n, p, i, acc);
+        } else {
+            const double a17 = (u[i] < 0 ? 1.0 : -1.0) * (double)(uint64_t)(1.7 * (double)p);
+            const uint64_t msf = adversarial ? p / 2 + 1 : key[(i + 1) % n];
+            const double msf_c = centre(msf), in = a17 - u[i];
+            const double out = hxf::mul_shoup(in, msf_c, msf_c / (double)p, m);
+            trackx(in); trackx(out);
+            CHECK(out == (double)(int64_t)out && centred((i128)(int64_t)in * (int64_t)msf_c - (int64_t)out, (int64_t)p) == 0,
+                  "mod-down epilogue on an X-schedule tail n=%lu p=%lu i=%lu", n, p, i);
+        }
+    }
+}
+
 // inverse without the w/p table, canonical input words as they are; lazy = the lazy kernels' schedule, else the strict one
 static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversarial, double rho = 1.0) {
     hxf::Mod m{(double)p, 1.0 / (double)p};
@@ -650,6 +719,30 @@ int main() {
                     for (int adv = 0; adv < 2; ++adv) { test_round4(n, p, period, hxf::LAZY_SKIP_MAX_RATIO, adv); test_inverse_nowp(n, p, true, adv); }
             std::printf("period %2d (p <= 2^%d): max |x| seen = 2^%.3f (limit 2^53)\n", period, tier == 0 ? 50 : 49, log2(g_max_abs));
             CHECK(g_max_abs < 9007199254740992.0, "lazy bound exceeded for period %d", period);
+        }
+        // round 6: the X schedules, every tier at its largest admissible prime = 1 mod 2^15, the bench primes and one prime well inside the tier;
+        // every transform size of the kernels, both input kinds, both consumers
+        for (int period : {3, 6, 12}) {
+            const uint64_t top = period == 3 ? (uint64_t)hxf::LAZY_MAX_MODULUS : period == 6 ? (1ull << 50) : (1ull << 49);
+            std::vector<uint64_t> tp;
+            for (uint64_t v = ((top - 1) / 32768) * 32768 + 1; tp.empty(); v -= 32768) if (v <= top && orc_is_prime(v)) tp.push_back(v);
+            if (period == 3) { tp.push_back(primes[0]); tp.push_back(primes[7]); }
+            orc_generate_primes(tmp, 2, period == 3 ? 50 : period == 6 ? 49 : 47, 16384); tp.push_back(tmp[0]);
+            g_xs_max = 0; g_xs_tail = 0;
+            for (uint64_t p : tp) {
+                CHECK(hxf::lazy_period_for((double)p) >= period, "prime %lu: tier %d not admissible", p, period);
+                for (uint64_t n : {1024ull, 2048ull, 4096ull, 8192ull, 16384ull, 32768ull}) {
+                    if (p % (2 * n) != 1) continue;                          // (15 stages: primes = 1 mod 2^16 only)
+                    for (int adv = 0; adv < 2; ++adv)
+                        for (int shift = 0; shift < 2; ++shift)
+                            for (int down = 0; down < 2; ++down) {
+                                test_xsched(n, p, period, shift, down, hxf::LAZY_SKIP_MAX_RATIO, adv);
+                                if (n == 16384) test_xsched(n, p, period, shift, down, 1.004, adv);
+                            }
+                }
+            }
+            std::printf("X schedules, period-%d tier (%d primes): max |x| seen = 2^%.3f (limit 2^53), largest tail %.3f p\n", period, (int)tp.size(), log2(g_xs_max), g_xs_tail);
+            CHECK(g_xs_max < 9007199254740992.0, "X schedule bound exceeded (tier %d)", period);
         }
     }
     // strict kernels (moduli up to 2^52): table-free inverse with both outputs reduced
