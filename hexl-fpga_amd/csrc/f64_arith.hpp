@@ -444,4 +444,83 @@ constexpr bool xsched_table_ok() {
 static_assert(xsched_table_ok(), "an X schedule of XSCHED_TABLE passes 2^53 (or its tail does not fit under the mod-down epilogue): regenerate with tools/gen_xsched.py");
 }  // namespace bounds
 
+// ---- "I schedules" (round 6): the inverse transforms' range reductions by butterfly history ---------------------------------------------
+// Gentleman-Sande without the w/p table: s = X + Y, d = X - Y, X' = s, Y' = mul_mod(d, w). With both inputs bounded by b p the sum and the
+// difference are bounded by 2 b p (both must stay below 2^53 = p / a) and |Y'| <= (0.5 + 1.5 a 2 b) p. The two inputs of a butterfly of
+// stage k + 1 have the same history -- both are sum outputs ("S") or both product outputs ("P") of stage k -- and inside a register pass
+// that history is a bit of the register index: a compile-time property of the butterfly. The periodic schedule above reduces EVERY sum
+// (3 instructions per butterfly and stage, plus the products of INV_NOWP_STRICT_STAGE) whatever the tier; an I schedule decides per
+// stage and history whether the sum and / or the product is reduced (at the first stage of a pass the history is a bit of the THREAD
+// index, so there the decision is the same for both kinds). tools/gen_isched.py brute-forces the cheapest schedule per tier (at its
+// largest modulus) and geometry (LOGN, LOGE: which stages open a pass), inputs taken as canonical words of a neighbouring modulus
+// (|x| <= LAZY_SKIP_MAX_RATIO p, which covers centred inputs); the last stage (n^-1 folded in, mul_shoup + reduce on both outputs)
+// is not part of the schedule and only needs its sum and difference below 2^53. N = 16384: 31.5 instead of 42 + 3 reduction instructions
+// per butterfly column in the top tier, 15 in the period-6 tier, 9 in the period-12 tier.
+// Encoding: four bits per global stage s (1-based, s < LOGN) at bits 4 (s - 1): 1 = reduce the sum of S-S butterflies, 2 = their product,
+// 4 = the sum of P-P butterflies, 8 = their product (comments: s p S P); bit 63 = entry present. bounds::isched_ok replays the recurrence
+// for every entry under static_assert; tests/cpp/f64_selftest.cpp replays whole transforms against exact integers.
+struct ISchedEntry { int period, logn, loge; unsigned long long mask; };
+constexpr ISchedEntry ISCHED_TABLE[] = {
+    { 3, 10, 4, 0x80000001c5454545ull},   // sS S sS S sS S sS PS s   21 (30)  3.871 of 3.969
+    { 3, 11, 4, 0x8000001c54545545ull},   // sS S sS sS S sS S sS PS s   24 (33)  3.926 of 3.969
+    { 3, 11, 5, 0x8000004510f45455ull},   // sS sS S sS S sPSp . s sS S   24 (33)  3.762 of 3.969
+    { 3, 12, 4, 0x8000010f45454545ull},   // sS S sS S sS S sS S sPSp . s   25.5 (36)  3.926 of 3.969
+    { 3, 12, 5, 0x800004510f454545ull},   // sS S sS S sS S sPSp . s sS S   25.5 (36)  3.798 of 3.969
+    { 3, 13, 4, 0x8000450d54545455ull},   // sS sS S sS S sS S sS sPS . sS S   28.5 (39)  3.926 of 3.969
+    { 3, 13, 5, 0x80004510f4545545ull},   // sS S sS sS S sS S sPSp . s sS S   28.5 (39)  3.871 of 3.969
+    { 3, 14, 4, 0x8005454d45454545ull},   // sS S sS S sS S sS S sPS S sS S sS   31.5 (42)  3.926 of 3.969
+    { 6, 10, 4, 0x8000000010451010ull},   // . s . s sS S . s .   9 (30)  7.750 of 8.000
+    { 6, 11, 4, 0x8000000104505010ull},   // . s . sS . sS S . s .   10.5 (33)  7.812 of 8.000
+    { 6, 11, 5, 0x8000001010451050ull},   // . sS . s sS S . s . s   12 (33)  7.000 of 8.000
+    { 6, 12, 4, 0x8000001051051010ull},   // . s . s sS . s sS . s .   12 (36)  7.823 of 8.000
+    { 6, 12, 5, 0x8000010104511010ull},   // . s . s s sS S . s . s   12 (36)  7.812 of 8.000
+    { 6, 13, 4, 0x8000010451010450ull},   // . sS S . s . s sS S . s .   13.5 (39)  7.117 of 8.000
+    { 6, 13, 5, 0x8000101045105010ull},   // . s . sS . s sS S . s . s   13.5 (39)  7.812 of 8.000
+    { 6, 14, 4, 0x8000105105111010ull},   // . s . s s s sS . s sS . s .   15 (42)  7.945 of 8.000
+    {12, 10, 4, 0x8000000010100500ull},   // . . sS . . s . s .   6 (30)  11.500 of 16.000
+    {12, 11, 4, 0x8000000050100100ull},   // . . s . . s . sS . .   6 (33)  15.500 of 16.000
+    {12, 11, 5, 0x8000000010100100ull},   // . . s . . s . s . .   4.5 (33)  15.500 of 16.000
+    {12, 12, 4, 0x8000010010100100ull},   // . . s . . s . s . . s   6 (36)  15.500 of 16.000
+    {12, 12, 5, 0x8000001001010010ull},   // . s . . s . s . . s .   6 (36)  14.305 of 16.000
+    {12, 13, 4, 0x8000010100500100ull},   // . . s . . sS . . s . s .   7.5 (39)  15.625 of 16.000
+    {12, 13, 5, 0x8000010010100100ull},   // . . s . . s . s . . s .   6 (39)  15.500 of 16.000
+    {12, 14, 4, 0x8000050010100500ull},   // . . sS . . s . s . . sS . .   9 (42)  14.676 of 16.000
+};
+constexpr int ISCHED_ENTRIES = sizeof(ISCHED_TABLE) / sizeof(ISCHED_TABLE[0]);
+constexpr unsigned long long ISCHED_PRESENT = 0x8000000000000000ull;
+HX_HD constexpr unsigned long long isched_mask(int period, int logn, int loge) {      // 0 = none: the periodic schedule
+    for (int i = 0; i < ISCHED_ENTRIES; ++i)
+        if (ISCHED_TABLE[i].period == period && ISCHED_TABLE[i].logn == logn && ISCHED_TABLE[i].loge == loge) return ISCHED_TABLE[i].mask;
+    return 0ull;
+}
+HX_HD constexpr int isched_bits(unsigned long long mask, int s) { return int((mask >> (4 * (s - 1))) & 15ull); }
+// does global stage s (1-based) open a register pass of the inverse transform of this geometry? (partial pass first: KL = LOGN - (P - 1) LOGE stages)
+HX_HD constexpr bool isched_opens_pass(int logn, int loge, int s) {
+    const int passes = (logn + loge - 1) / loge, kl = logn - (passes - 1) * loge;
+    return s == 1 || (s > kl && (s - kl - 1) % loge == 0);
+}
+namespace bounds {
+constexpr bool isched_ok(const ISchedEntry& e) {
+    if (!(e.mask & ISCHED_PRESENT) || e.logn > 15) return false;
+    const double a = tier_a(e.period), limit = 1.0 / a, r = 0.5 + SLOP;
+    double bs = LAZY_SKIP_MAX_RATIO, bp = LAZY_SKIP_MAX_RATIO;       // bounds of the sum outputs / product outputs of the previous stage
+    for (int s = 1; s < e.logn; ++s) {
+        const int bits = isched_bits(e.mask, s);
+        if (isched_opens_pass(e.logn, e.loge, s) && ((bits & 3) != ((bits >> 2) & 3))) return false;   // history not known at compile time there
+        if (!(2.0 * bs < limit) || !(2.0 * bp < limit)) return false;                                   // |X + Y|, |X - Y|
+        const double s_from_s = (bits & 1) ? r : 2.0 * bs, p_from_s = (bits & 2) ? r : 0.5 + 1.5 * a * 2.0 * bs;
+        const double s_from_p = (bits & 4) ? r : 2.0 * bp, p_from_p = (bits & 8) ? r : 0.5 + 1.5 * a * 2.0 * bp;
+        bs = s_from_s > s_from_p ? s_from_s : s_from_p;
+        bp = p_from_s > p_from_p ? p_from_s : p_from_p;
+    }
+    return 2.0 * bs < limit && 2.0 * bp < limit;                      // the fused last stage's sum and difference
+}
+constexpr bool isched_table_ok() {
+    for (int i = 0; i < ISCHED_ENTRIES; ++i)
+        if (!isched_ok(ISCHED_TABLE[i])) return false;
+    return true;
+}
+static_assert(isched_table_ok(), "an I schedule of ISCHED_TABLE passes 2^53 or decides by history where a pass opens: regenerate with tools/gen_isched.py");
+}  // namespace bounds
+
 }  // namespace hxf

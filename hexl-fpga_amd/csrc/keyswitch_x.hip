@@ -208,6 +208,11 @@ constexpr int KX_PF = KX_PF_DEPTH;
 #ifndef KX_XSCHED
 #define KX_XSCHED 1
 #endif
+// ... and the inverse transforms (k_ksx_intt, the special slot's two) the I schedules: sums and products range-reduced by the history of the
+// butterfly's inputs instead of every sum at every stage (N = 16384, top tier: 31.5 instead of 45 reduction instructions per butterfly column)
+#ifndef KX_ISCHED
+#define KX_ISCHED 1
+#endif
 // FOLD: the folded multiply-accumulate (f64_arith.hpp mac_fold; lazy tiers: accumulators <= 1.6p between rounds, strict tier <= 0.9p)
 // CSW: words between the two key components of a row (0: G::N; the N = 32768 kernels work on HALF rows of rows that are 2 G::N long)
 template <class G, bool FOLD = false, int CSW = 0>
@@ -325,7 +330,7 @@ __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __re
 template <int LOGN, int LOGE, int LAZY, bool FUSED = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
-    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, true>;            // inverse without the w/p table
+    using W = WgNttF64<LOGN, LOGE, LAZY, 0, 0, true, HX_FWD_PRIO, 0, false, -1, KX_ISCHED != 0>;            // inverse without the w/p table
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.nsel);
     if (wk.pos >= wk.end) return;
@@ -390,7 +395,7 @@ template <int LOGN, int LOGE, int LAZY, bool SKIP = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_special(KsArgsX a) {
     using G = Geom<LOGN, LOGE>;
     static_assert(!SKIP || LAZY != 0, "SKIP is a lazy-kernel variant");
-    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY), KX_XSCHED ? 0 : -1>;   // forward output -> mac_fold
+    using W = WgNttF64<LOGN, LOGE, LAZY, KX_PRE, SKIP ? 1 : 0, true, HX_FWD_PRIO, 0, KX_SEMIU_ON(LAZY), KX_XSCHED ? 0 : -1, KX_ISCHED != 0>;   // forward output -> mac_fold
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const u32 L = a.L;
     const u32 isp = a.K - 1;

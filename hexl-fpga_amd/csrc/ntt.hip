@@ -40,6 +40,10 @@ using namespace hx;
 #ifndef NTT_XSCHED
 #define NTT_XSCHED 1
 #endif
+// ... and the inverse transform on the I schedule (range reductions by the history of a butterfly's inputs). 0 = every sum at every stage.
+#ifndef NTT_ISCHED
+#define NTT_ISCHED 1
+#endif
 // (the kernels' SEMI parameter: strict tier with the semi-strict butterflies in the WAVE-UNIFORM passes, ntt_core_f64.hpp SEMIU)
 
 // ---------------------------------------------------------------------------------------------
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_x(u64* __restric
         out_of_range |= raw >= limit;
         f[r] = fast_path_input<LAZY>(raw, m);
     }
-    WgNttF64<LOGN, LOGE, LAZY, 0, 0, true>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
+    WgNttF64<LOGN, LOGE, LAZY, 0, 0, true, HX_FWD_PRIO, 0, false, -1, NTT_ISCHED != 0>::template inverse<true>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc);   // no w/p table
     const bool slow = __syncthreads_or(out_of_range);                            // see k_ntt_fwd_x
     if (!slow) {
         fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 #pragma unroll
             for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
         };
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, true>::template inverse<false, decltype(request_next), (NTT_IPRE != 0)>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_next);   // no w/p table
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, true, HX_FWD_PRIO, 0, false, -1, NTT_ISCHED != 0>::template inverse<false, decltype(request_next), (NTT_IPRE != 0)>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_next);   // no w/p table
         const bool slow = vote.result(tid);
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });

@@ -131,9 +131,19 @@ __device__ __forceinline__ void fwd_stages_f64_ahead(double (&v)[E], u32 G, cons
 using hxf::InvScale;
 
 // one inverse butterfly of global stage `gs` (1-based); NOWP: no w/p table (f64_arith.hpp gs_bfly_lazy_nowp)
-template <int LAZY, bool NOWP>
-__device__ __forceinline__ void inv_bfly(double& X, double& Y, double W, double Wp, const Mod m, int gs) {
-    if constexpr (NOWP) {
+// IS != 0 (round 6, lazy kernels without the w/p table): an I schedule of f64_arith.hpp (isched_mask) decides per stage and per history of
+// the two inputs -- `from_products`: both are product outputs of the previous stage (a bit of the register index inside a pass; at the
+// first stage of a pass the schedule holds the same decision for both kinds, so callers pass false) -- which outputs are range-reduced
+template <int LAZY, bool NOWP, unsigned long long IS = 0ull>
+__device__ __forceinline__ void inv_bfly(double& X, double& Y, double W, double Wp, const Mod m, int gs, bool from_products = false) {
+    if constexpr (IS != 0ull) {
+        static_assert(LAZY > 0 && NOWP, "I schedules: lazy kernels without the w/p table");
+        const int bits = hxf::isched_bits(IS, gs) >> (from_products ? 2 : 0);
+        const double s = X + Y, d = X - Y;
+        X = (bits & 1) ? hxf::reduce(s, m) : s;
+        const double t = hxf::mul_mod(d, W, m);
+        Y = (bits & 2) ? hxf::reduce(t, m) : t;
+    } else if constexpr (NOWP) {
         if (LAZY && gs != hxf::INV_NOWP_STRICT_STAGE) hxf::gs_bfly_lazy_nowp(X, Y, W, m);
         else hxf::gs_bfly_nowp(X, Y, W, m);
     } else {
@@ -142,7 +152,7 @@ __device__ __forceinline__ void inv_bfly(double& X, double& Y, double W, double 
     }
 }
 
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, bool NOWP = false>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool UNI = false, bool NOWP = false, unsigned long long IS = 0ull>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -162,7 +172,7 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
                 const int a0 = OFF + (j << (u + 1)) + c;
                 const int a1 = a0 + (1 << u);
                 if (!fused) {
-                    inv_bfly<LAZY, NOWP>(v[a0], v[a1], W, Wp, m, LO + u + 1);
+                    inv_bfly<LAZY, NOWP, IS>(v[a0], v[a1], W, Wp, m, LO + u + 1, u > 0 && ((c >> (u > 0 ? u - 1 : 0)) & 1));
                 } else {                                   // last stage: scale both outputs by n^-1
                     const double s = v[a0] + v[a1], d = v[a0] - v[a1];
                     v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
@@ -176,7 +186,7 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[E], u32 G, const doub
 // The same K inverse stages with all their 2^K - 1 twiddle pairs requested before the first butterfly (IPRE, kernels with
 // registers to spare: k_ksx_intt). Left alone the compiler requests each pair right in front of its use and waits for it:
 // up to 15 exposed latencies per per-lane pass.
-template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool NOWP = false>
+template <int E, int OFF, int K, int LO, int LOGN, bool LAST, int LAZY = 0, bool NOWP = false, unsigned long long IS = 0ull>
 __device__ __forceinline__ void inv_stages_f64_pre(double (&v)[E], u32 G, const double* __restrict__ iw,
                                                    const double* __restrict__ iwp, const Mod m, const InvScale sc) {
     constexpr u32 N = 1u << LOGN;
@@ -207,7 +217,7 @@ __device__ __forceinline__ void inv_stages_f64_pre(double (&v)[E], u32 G, const 
                 const int a0 = OFF + (j << (u + 1)) + c;
                 const int a1 = a0 + (1 << u);
                 if (!fused) {
-                    inv_bfly<LAZY, NOWP>(v[a0], v[a1], W, Wp, m, LO + u + 1);
+                    inv_bfly<LAZY, NOWP, IS>(v[a0], v[a1], W, Wp, m, LO + u + 1, u > 0 && ((c >> (u > 0 ? u - 1 : 0)) & 1));
                 } else {
                     const double s = v[a0] + v[a1], d = v[a0] - v[a1];
                     v[a0] = hxf::reduce(hxf::mul_shoup(s, sc.n, sc.n_p, m), m);
@@ -275,8 +285,12 @@ __device__ __forceinline__ void hx_inv_prio() {
 // XSD (round 6, lazy kernels): -1 = the periodic reduction schedule; 0 / 1 = the X schedule of f64_arith.hpp for this tier, input kind
 // (FSHIFT) and transform size, chosen for a consumer that takes any tail below 2^53 (mac_fold, or FINAL's range reduction: 0) or for the
 // mod-down epilogue (un-reduced accumulator minus the tail: 1). Strict kernels keep their schedules.
-template <int LOGN, int LOGE, int LAZY = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, int TOP = 0, bool SEMIU = false, int XSD = -1>
+// ISD (round 6, lazy kernels without the w/p table, TOP == 0): the inverse transform on the I schedule of f64_arith.hpp for this tier and geometry
+// (none in the table: the periodic schedule)
+template <int LOGN, int LOGE, int LAZY = 0, int PRE = 0, int FSHIFT = 0, bool NOWP = false, int FPRIO = HX_FWD_PRIO, int TOP = 0, bool SEMIU = false, int XSD = -1,
+          bool ISD = false>
 struct WgNttF64 {
+    static constexpr unsigned long long IS = (ISD && LAZY > 0 && NOWP && TOP == 0) ? hxf::isched_mask(LAZY, LOGN, LOGE) : 0ull;
     static_assert(!SEMIU || LAZY == 0, "semi-strict uniform passes: strict kernels");
     using G = Geom<LOGN, LOGE>;
     static constexpr int E = G::E;
@@ -398,8 +412,8 @@ struct WgNttF64 {
                                                      const Mod m, const InvScale sc, u32 top = 0) {
         if constexpr (GRP < G::NG) {
             const u32 Gbits = ginv<0, G::KL>(top, u32(G::grpB(GRP, tid)));
-            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, NOWP>(v, Gbits, iw, iwp, m, sc);
-            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, false, NOWP>(v, Gbits, iw, iwp, m, sc);
+            if constexpr (IPRE) inv_stages_f64_pre<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, NOWP, IS>(v, Gbits, iw, iwp, m, sc);
+            else inv_stages_f64<E, GRP * (1 << G::KL), G::KL, 0, FLOGN, (G::P == 1 && TOP == 0), LAZY, false, NOWP, IS>(v, Gbits, iw, iwp, m, sc);
             inv_first<GRP + 1, IPRE>(v, tid, iw, iwp, m, sc, top);
         }
     }
@@ -421,8 +435,8 @@ struct WgNttF64 {
             const u32 Gl = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             const u32 Gp = ginv<LO, LOGE>(top, Gl);
             // (TOP > 0: the transform's last stage -- the one with n^-1 folded in -- is not among these)
-            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, FLOGN, false, LAZY, NOWP>(v, Gp, iw, iwp, m, sc);
-            else inv_stages_f64<E, 0, LOGE, LO, FLOGN, (PASS == G::P - 2 && TOP == 0), LAZY, (PASS == G::P - 2 || LO >= 6), NOWP>(v, Gp, iw, iwp, m, sc);
+            if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, FLOGN, false, LAZY, NOWP, IS>(v, Gp, iw, iwp, m, sc);
+            else inv_stages_f64<E, 0, LOGE, LO, FLOGN, (PASS == G::P - 2 && TOP == 0), LAZY, (PASS == G::P - 2 || LO >= 6), NOWP, IS>(v, Gp, iw, iwp, m, sc);
             inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform, top);
         }
     }

@@ -453,6 +453,59 @@ static void test_inverse_nowp(uint64_t n, uint64_t p, bool lazy, bool adversaria
     for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "nowp inverse n=%lu p=%lu lazy=%d i=%lu", n, p, (int)lazy, i);
 }
 
+// round 6: the I schedules (f64_arith.hpp ISCHED_TABLE; ntt_core_f64.hpp inv_bfly<..., IS>): the table-free inverse with the range
+// reductions the table names, decided per stage and per history of the butterfly's inputs (both sum outputs / both product outputs of
+// the previous stage; at the stages that open a register pass of the (logn, loge) geometry the table holds one decision for both),
+// canonical words below rho p as they are, the fused last stage as the device runs it
+static double g_is_max = 0;
+static void test_isched(uint64_t n, int loge, uint64_t p, int period, bool adversarial, double rho) {
+    hxf::Mod m{(double)p, 1.0 / (double)p};
+    int logn = 0; while ((1ull << logn) < n) ++logn;
+    const unsigned long long mask = hxf::isched_mask(period, logn, loge);
+    CHECK(mask != 0ull, "no I schedule for period %d logn %d loge %d", period, logn, loge);
+    std::vector<uint64_t> blk(4 * n);
+    orc_tables_keyswitch(n, p, orc_minimal_primitive_root(2 * n, p), blk.data());
+    const uint64_t* inv0 = blk.data();
+    auto centre = [&](uint64_t v) { return hxf::reduce(hxf::to_f64(v), m); };
+    auto tracki = [&](double x) { const double a = x < 0 ? -x : x; if (a > g_is_max) g_is_max = a; };
+    const uint64_t top = (uint64_t)(rho * (double)p) - 1;
+    std::vector<uint64_t> x(n), ref;
+    for (uint64_t i = 0; i < n; ++i) x[i] = adversarial ? ((i & 1) ? top : ((i & 2) ? 0 : top - 1)) : rnd() % (top + 1);
+    ref = x;
+    for (auto& v : ref) v %= p;
+    orc_ks_intt(ref.data(), n, p, inv0);
+    std::vector<double> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = hxf::to_f64_lt52(x[i]);
+    const double ninv = centre(orc_invmod(n, p)), ninv_p = ninv / (double)p;
+    const double nw = centre(orc_mulmod(orc_invmod(n, p), inv0[n - 2], p)), nw_p = nw / (double)p;
+    uint64_t acc = 0;
+    int gs = 1;
+    for (uint64_t mm = n >> 1, t = 1; mm >= 1; mm >>= 1, t <<= 1, ++gs) {
+        const bool opens = hxf::isched_opens_pass(logn, loge, gs);
+        for (uint64_t i = 0; i < mm; ++i) {
+            const double w = centre(inv0[acc + i]);
+            for (uint64_t j = 2 * i * t; j < 2 * i * t + t; ++j) {
+                const double sum = v[j] + v[j + t], dif = v[j] - v[j + t];
+                tracki(sum); tracki(dif);
+                if (mm > 1) {
+                    // history: the previous stage paired (k, k + t / 2): its product outputs sit where bit t / 2 of the index is set
+                    const bool from_products = !opens && t > 1 && (j & (t >> 1)) != 0;
+                    const int bits = hxf::isched_bits(mask, gs) >> (from_products ? 2 : 0);
+                    const double pr = hxf::mul_mod(dif, w, m);
+                    tracki(pr);
+                    v[j] = (bits & 1) ? hxf::reduce(sum, m) : sum;
+                    v[j + t] = (bits & 2) ? hxf::reduce(pr, m) : pr;
+                } else {
+                    v[j] = hxf::reduce(hxf::mul_shoup(sum, ninv, ninv_p, m), m);
+                    v[j + t] = hxf::reduce(hxf::mul_shoup(dif, nw, nw_p, m), m);
+                }
+            }
+        }
+        acc += mm;
+    }
+    for (uint64_t i = 0; i < n; ++i) CHECK(hxf::from_f64(hxf::lift(v[i], m)) == ref[i], "I schedule inverse n=%lu loge=%d p=%lu (period %d) i=%lu", n, loge, p, period, i);
+}
+
 // STRICT butterflies at moduli in [2^52, STRICT_NTT_MAX_Q) -- the standalone _NTT / _INTT fast path of ntt.hip for SURVEY 8d's
 // q = 2^52 + 393217: forward (ct_bfly) and table-free inverse (gs_bfly_nowp, fused last stage on mul_shoup) with the device's own
 // conversions (reduce(to_f64(raw)) in, from_f64_53(lift()) out), against the oracle, tracking every intermediate magnitude
@@ -741,6 +794,15 @@ int main() {
                             }
                 }
             }
+            g_is_max = 0;
+            for (uint64_t p : tp)
+                for (auto ge : {std::pair<uint64_t, int>{1024, 4}, {2048, 4}, {2048, 5}, {4096, 4}, {4096, 5}, {8192, 4}, {8192, 5}, {16384, 4}})
+                    for (int adv = 0; adv < 2; ++adv) {
+                        test_isched(ge.first, ge.second, p, period, adv, hxf::LAZY_SKIP_MAX_RATIO);
+                        test_isched(ge.first, ge.second, p, period, adv, 1.0);
+                    }
+            std::printf("I schedules, period-%d tier (%d primes): max |x| seen = 2^%.3f (limit 2^53)\n", period, (int)tp.size(), log2(g_is_max));
+            CHECK(g_is_max < 9007199254740992.0, "I schedule bound exceeded (tier %d)", period);
             std::printf("X schedules, period-%d tier (%d primes): max |x| seen = 2^%.3f (limit 2^53), largest tail %.3f p\n", period, (int)tp.size(), log2(g_xs_max), g_xs_tail);
             CHECK(g_xs_max < 9007199254740992.0, "X schedule bound exceeded (tier %d)", period);
         }
