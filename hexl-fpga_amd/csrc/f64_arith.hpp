@@ -237,7 +237,7 @@ constexpr double LAZY_SKIP_MAX_RATIO = 1.25;
 //   p <= 2^50:         a = 0.125, limit 8:    0.5 -> 1.09 -> 1.80 -> 2.64 -> 3.63 -> 4.81 -> 6.22  period 6
 //   p <= 2^49:         a = 0.0625, limit 16:  ... -> 11.8 after twelve stages                      period 12
 // (consumers of an un-reduced tail need c + 0.5 < 1/a: at most two tail stages follow a reduction for n <= 2^14.)
-// The inverse schedule does not change with the tier. tests/cpp/f64_selftest.cpp replays every tier.
+// The PERIODIC inverse schedule does not change with the tier (the I schedules further down do). tests/cpp/f64_selftest.cpp replays every tier.
 HX_HD constexpr int lazy_period_for(double max_modulus) {
     return max_modulus <= 562949953421312.0 ? 12 : max_modulus <= 1125899906842624.0 ? 6 : max_modulus <= LAZY_MAX_MODULUS ? 3 : 0;
 }
