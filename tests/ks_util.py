@@ -5,7 +5,7 @@ import numpy as np
 
 
 class KsCase:
-    def __init__(self, orc, n, L, K, seed=1, bits=51, with_twiddles=False, moduli=None):
+    def __init__(self, orc, n, L, K, seed=1, bits=51, with_twiddles=False, moduli=None, extreme_keys=False):
         self.n, self.L, self.K, self.rns = n, L, K, L + 1
         self.moduli = np.array(orc.primes(K, bits, n) if moduli is None else moduli, dtype=np.uint64)
         q_sp = int(self.moduli[K - 1])
@@ -16,8 +16,9 @@ class KsCase:
             k = np.empty(2 * K * n, dtype=np.uint64)
             for kk in range(2):
                 for i in range(K):
-                    k[(kk * K + i) * n:(kk * K + i + 1) * n] = orc.splitmix(n, seed * 7919 + d * 131 + kk * 17 + i,
-                                                                           int(self.moduli[i]))
+                    k[(kk * K + i) * n:(kk * K + i + 1) * n] = (
+                        extreme_words(n, int(self.moduli[i]), d + kk + i) if extreme_keys else
+                        orc.splitmix(n, seed * 7919 + d * 131 + kk * 17 + i, int(self.moduli[i])))
             self.keys.append(k)
         self.twiddles = None
         if with_twiddles:
@@ -36,10 +37,27 @@ class KsCase:
                             for k in range(2) for i in range(L)])
         return t, r
 
+    def extreme_inputs(self, orc, b):
+        """instance b of a worst-case family: every word at an end of the residue range or beside its middle (the largest
+        magnitudes of the centred representation the FP64 kernels compute in), in runs and alternations that line signs up"""
+        n, L = self.n, self.L
+        t = np.concatenate([extreme_words(n, int(self.moduli[d]), b * 5 + d) for d in range(L)])
+        r = np.concatenate([extreme_words(n, int(self.moduli[i]), b * 7 + k * 3 + i + 1) for k in range(2) for i in range(L)])
+        return t, r
+
     def expected(self, orc, t, r):
         out = r.copy()
         orc.keyswitch(out, t, self.n, self.L, self.K, self.rns, self.moduli, self.keys, self.modswitch, self.twiddles)
         return out
+
+
+def extreme_words(n, q, which):
+    """n words below q from {q - 1, (q - 1) / 2, (q + 1) / 2, 0, 1} -- constant, alternating, in halves or in runs of 16"""
+    lo, hi, top = (q - 1) // 2, (q + 1) // 2, q - 1
+    j = np.arange(n)
+    pats = [np.full(n, top), np.full(n, lo), np.full(n, hi), np.where(j & 1, hi, lo), np.where(j < n // 2, lo, hi),
+            np.where(j & 1, top, 1), np.where((j >> 4) & 1, hi, top), np.where(j & 2, lo, top), np.where(j & 1, 0, hi)]
+    return pats[which % len(pats)].astype(np.uint64)
 
 
 def primes_below(orc, count, limit, n):
@@ -49,6 +67,16 @@ def primes_below(orc, count, limit, n):
         if v < limit and orc.orc().orc_is_prime(v):
             out.append(v)
         v -= 2 * n
+    return out
+
+
+def primes_from(orc, count, start, n):
+    """the `count` smallest primes p >= start with p = 1 (mod 2n), ascending"""
+    out, v = [], (start + 2 * n - 2) // (2 * n) * (2 * n) + 1
+    while len(out) < count:
+        if orc.orc().orc_is_prime(v):
+            out.append(v)
+        v += 2 * n
     return out
 
 

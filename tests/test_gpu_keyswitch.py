@@ -452,6 +452,9 @@ TIERS = {
     "noskip_period6_mixed_50_to_40bit": ({}, "primes_below(orc, 2, 1 << 50, n) + orc.primes(K - 3, 40, n) + orc.primes(1, 45, n)"),
     "noskip_period3_mixed_51_and_30bit": ({}, "orc.primes(2, 51, n)[:1] + orc.primes(K - 2, 30, n) + orc.primes(2, 51, n)[1:]"),
     "strict_just_below_2^52": ({}, "primes_below(orc, K, 1 << 52, n)"),
+    # round 6: both sides of the lazy / strict boundary 2^51 (1 + 2^-7) (f64_arith.hpp LAZY_MAX_MODULUS)
+    "period3_tier_top_2^51_plus_2^44": ({}, "primes_below(orc, K, (1 << 51) + (1 << 44), n)"),
+    "strict_just_above_2^51_plus_2^44": ({}, "primes_from(orc, K, (1 << 51) + (1 << 44), n)"),
     "strict_forced_51bit": ({"HEXL_KS_NOLAZY": "1"}, "None"),
     # round 5: plans whose limbs differ in tier -- every transform takes the tier of ITS modulus (hexl_ks_plan::tier; the reference's NTT
     # engines each run on their own modulus, device/keyswitch/ntt_core.hpp:285-291)
@@ -476,6 +479,25 @@ MIXED_TIERS_K4 = {
 def test_slot_major_kernels_in_every_tier(tier, n, L, K, nb):
     env, moduli = TIERS[tier]
     _alternative(dict(env, HEXL_KS_PIPE="3"), n, L, K, nb, moduli)
+
+
+# Round 6: the X / I reduction schedules leave sums un-reduced wherever the worst-case bound chain allows it. Uniform inputs stay far
+# from those bounds; these do not try to reach them (no input does on all 14 stages) but start every chain at its largest magnitudes:
+# every word of the keys, t_target and result at q - 1, beside q / 2, 0 or 1, constant / alternating / in runs (ks_util.extreme_words)
+EXTREME_TIERS = ["skip_period3_51bit", "period3_tier_top_2^51_plus_2^44", "strict_just_above_2^51_plus_2^44", "skip_period6_just_below_2^50",
+                 "skip_period12_just_below_2^49", "strict_just_below_2^52", "mixed_seal_chain_strict_and_period12", "mixed_all_four_tiers"]
+
+
+@pytest.mark.parametrize("tier", EXTREME_TIERS)
+@pytest.mark.parametrize("n,L,K,nb,env", [(16384, 3, 4, 300, {"HEXL_KS_PIPE": "3"}), (16384, 3, 4, 9, {"HEXL_KS_LAT": "0"}),
+                                          (16384, 3, 4, 3, {"HEXL_KS_LAT": "2"}), (32768, 3, 4, 90, {})])
+def test_extreme_residues_in_every_tier(tier, n, L, K, nb, env):
+    """slot-major kernels in every tier; the (b, d)-major kernels, the quarter-transform latency path and the N = 32768 halves in three"""
+    if "HEXL_KS_PIPE" not in env and tier not in ("period3_tier_top_2^51_plus_2^44", "strict_just_below_2^52",
+                                                  "mixed_seal_chain_strict_and_period12"):
+        pytest.skip("pipeline covered in three tiers")
+    tenv, moduli = TIERS[tier]
+    _alternative(dict(tenv, **env), n, L, K, nb, moduli, extreme=True)
 
 
 @pytest.mark.parametrize("L,K,nb,env", [(3, 4, 80, {}), (6, 7, 40, {}), (1, 2, 230, {}), (15, 16, 3, {"HEXL_KS_PIPE": "3"}),
@@ -559,8 +581,9 @@ def test_latency_paths_agree_on_one_keyswitch(hx, ctx, dev, orc):
     plan.close()
 
 
-def _alternative(env, n, L, K, nb, moduli="None"):
-    """`nb` instances (three distinct ones repeated) through the library in a child process with `env` set, against the oracle"""
+def _alternative(env, n, L, K, nb, moduli="None", extreme=False):
+    """`nb` instances (three distinct ones repeated) through the library in a child process with `env` set, against the oracle
+    (`extreme`: keys and inputs from ks_util.extreme_words instead of uniform ones)"""
     import os
     import subprocess
     import sys
@@ -568,19 +591,20 @@ def _alternative(env, n, L, K, nb, moduli="None"):
 import sys
 sys.path[:0] = [%r, %r, %r]
 import numpy as np, torch, hexl_fpga_amd as hx, orc
-from ks_util import KsCase, primes_below, seal_chain, tier_ladder
+from ks_util import KsCase, primes_below, primes_from, seal_chain, tier_ladder
 dev = torch.device("cuda:0"); ctx = hx.Context(0)
 n, L, K, nb = %d, %d, %d, %d
-case = KsCase(orc, n, L, K, seed=77, moduli=%s)
+extreme = %s
+case = KsCase(orc, n, L, K, seed=77, moduli=%s, extreme_keys=extreme)
 plan = hx.KeySwitchPlan(ctx, n, L, K, K, 2, case.moduli, case.modswitch); plan.set_keys(case.keys)
-ins = [case.inputs(orc, b) for b in range(3)]
+ins = [case.extreme_inputs(orc, b) if extreme else case.inputs(orc, b) for b in range(3)]
 d_t = hx.as_i64(np.concatenate([ins[b %% 3][0] for b in range(nb)])).to(dev)
 d_r = hx.as_i64(np.concatenate([ins[b %% 3][1] for b in range(nb)])).to(dev)
 plan.keyswitch(d_r, d_t, nb); ctx.sync()
 out = hx.to_u64(d_r).reshape(nb, -1)
 want = [case.expected(orc, t, r) for t, r in ins]
 print("OK" if all(np.array_equal(out[b], want[b %% 3]) for b in range(nb)) else "MISMATCH")
-''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"), n, L, K, nb, moduli)
+''' % (str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests"), n, L, K, nb, extreme, moduli)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     print(out.stdout[-500:], out.stderr[-1500:])
     assert out.returncode == 0 and out.stdout.strip().endswith("OK")

@@ -75,6 +75,23 @@ def test_all_sizes_random(hx, ctx, dev, orc, n):
     assert np.array_equal(run_inv(hx, ctx, dev, x, t), orc.ntt_inv(x, t))
 
 
+@pytest.mark.parametrize("limit", [(1 << 52) + (1 << 49), 1 << 52, (1 << 51) + (1 << 44), 1 << 50, 1 << 49, 1 << 30],
+                         ids=["strict_top_2^52x1.125", "strict_2^52", "period3_top", "period6_top", "period12_top", "30bit"])
+@pytest.mark.parametrize("n", [16384, 32768, 2048])
+def test_extreme_residues_at_every_tier_top(hx, ctx, dev, orc, limit, n):
+    """Round 6 (X / I reduction schedules): the largest prime of every FP64 tier, polynomials whose words all sit at q - 1, beside q / 2,
+    at 0 or 1 -- constant, alternating, in halves and runs (ks_util.extreme_words) --, in a batch large enough for the persistent kernels"""
+    from ks_util import extreme_words, primes_below
+    q = primes_below(orc, 1, limit, n)[0]
+    t = orc.HexlTables(n, q)
+    base = np.stack([extreme_words(n, q, k) for k in range(9)])
+    batch = 300 * 16384 // n + 4
+    x = base[np.arange(batch) % 9].copy()
+    for run, ref in ((run_fwd, orc.ntt_fwd), (run_inv, orc.ntt_inv)):
+        got, want = run(hx, ctx, dev, x, t), ref(base, t)
+        assert (got == want[np.arange(batch) % 9]).all()
+
+
 def test_random_tables_like_benchmark(hx, ctx, dev, orc):
     """benchmark/bench_fwd_ntt.cpp:38-42 feeds RANDOM tables: the kernel must replay the butterflies
     op for op, not rely on the tables being roots of unity"""

@@ -143,6 +143,20 @@ class MatrixModel:
         return np.array([int(v) for v in out], dtype=np.uint64)
 
 
+@pytest.mark.parametrize("bits", [30, 51, 52])
+def test_oracle_vs_independent_models_on_extreme_residues(orc, bits):
+    """the worst-case family of the round-6 GPU tests (ks_util.extreme_words: every word at q - 1, beside q / 2, 0 or 1): the oracle
+    against the pure-Python model at n = 64 and against the matrix model at n = 1024"""
+    from ks_util import primes_below
+    for n, L, K, model in ((64, 3, 4, None), (1024, 2, 3, "matrix")):
+        moduli = primes_below(orc, K, 1 << bits, n)
+        case = KsCase(orc, n, L, K, seed=5, moduli=moduli, extreme_keys=True)
+        for b in range(3):
+            t, r = case.extreme_inputs(orc, b)
+            want = model_keyswitch(case, t, r, orc) if model is None else MatrixModel(orc, case).keyswitch(t, r)
+            assert np.array_equal(case.expected(orc, t, r), want)
+
+
 @pytest.mark.parametrize("L,K", [(1, 2), (2, 3), (6, 7)])
 def test_oracle_vs_independent_model_at_baseline_modulus_size(orc, L, K):
     n = 1024

@@ -3,7 +3,8 @@
 power, shader clock and mJ per keyswitch for HEXL_KS_CHUNK x HEXL_KS_LANES, one subprocess per leg (both knobs are read once per
 process), legs interleaved `rounds` times. Scratch per instance at L = 7: c[7][n] + s'[2][n] = 1.18 MB, so 2 lanes x 64 = 151 MB
 (+ 15 MB of keys + 3.7 MB of tables) fits the Infinity Cache, 2 x 256 = 604 MB (the default) does not.
-usage: chunk_energy_sweep.py [batch] [seconds per leg] [rounds]"""
+usage: chunk_energy_sweep.py [batch] [seconds per leg] [rounds] [legs, e.g. 73x2,146x2,256x2] [exact]
+"exact" rounds every leg's batch down to a multiple of its chunk (no ragged last chunk)."""
 import json
 import os
 import subprocess
@@ -62,11 +63,15 @@ if __name__ == "__main__":
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    if len(sys.argv) > 4:
+        LEGS = [tuple(int(x) for x in l.split("x")) for l in sys.argv[4].split(",")]
+    exact = len(sys.argv) > 5 and sys.argv[5] == "exact"
     print(f"# batch {batch}, {seconds} s per leg, {rounds} interleaved rounds; scratch per lane = chunk x 1.18 MB")
     for r in range(rounds):
         for chunk, lanes in LEGS:
             env = dict(os.environ, HEXL_KS_CHUNK=str(chunk), HEXL_KS_LANES=str(lanes))
-            out = subprocess.run([sys.executable, __file__, "--leg", str(batch), str(seconds)], env=env, capture_output=True, text=True)
+            lb = batch // chunk * chunk if exact else batch
+            out = subprocess.run([sys.executable, __file__, "--leg", str(lb), str(seconds)], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1]) if line else {"error": out.stderr[-200:]}
-            print(f"round {r} chunk {chunk:4d} lanes {lanes} scratch {chunk * lanes * 1.18:6.0f} MB: " + json.dumps(d), flush=True)
+            print(f"round {r} chunk {chunk:4d} lanes {lanes} batch {lb} scratch {chunk * lanes * 1.18:6.0f} MB: " + json.dumps(d), flush=True)
