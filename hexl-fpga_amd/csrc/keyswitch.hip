@@ -128,6 +128,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_modup(KsArgs a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) s0[G::idxA(r, tid)] = csub(acc0[r] + md.half, q);
         it = tb + opaque_zero() + 2 * G::N;
+        __syncthreads();                                // inverse after inverse: the first one's cross-wave readers (ntt_core.hpp ReadersGate; once per instance here)
         W::inverse(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
         u64* s1 = a.s + (size_t(b) * 2 + 1) * G::N;
 #pragma unroll
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_special(KsArgs a) {
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (s0 + G::idxA(r, 0))[u32(tid)] = csub(acc0[r] + md.half, q);
     }
+    __syncthreads();                                    // inverse after inverse: the first one's cross-wave readers (ntt_core.hpp ReadersGate; once per instance here)
     {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));

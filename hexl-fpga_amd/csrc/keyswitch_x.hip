@@ -312,10 +312,12 @@ __device__ __forceinline__ int in_pos(int r, int tid) { return G::KL <= 2 ? G::i
 // (intt2_redu.hpp:31-32, 49-51) -- that is, y_k = s'_k - floor(q_sp/2), the EXACT centred remainder of the inverse transform's
 // output in [-floor(q_sp/2), floor(q_sp/2)]. The scratch holds y_k (a signed integer in a double): k_ksx_main needs neither
 // the addition nor, when the moduli are of one size, a range reduction (|y_k| <= 0.5 rho q_i).
+// (`gate`: the second of the two inverse transforms follows the first one's cross-wave reads -- ntt_core.hpp ReadersGate)
 template <class G, class W>
 __device__ __forceinline__ void ksx_special_down(double (&v)[G::E], double* __restrict__ dst, double* lds, int tid,
-                                                 const double* ts, const KsModF64& msp) {
-    W::template inverse<false>(v, lds, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc);
+                                                 const double* ts, const KsModF64& msp, ReadersGate<G>& gate) {
+    W::template inverse<false, typename W::NoHook, false, ReadersGate<G>>(v, lds, tid, ts + 2 * G::N, ts + 3 * G::N, msp.m, msp.sc,
+                                                                         typename W::NoHook(), 0u, &gate);
 #pragma unroll
     for (int r = 0; r < G::E; ++r) {
         const double c = hxf::lift(v[r], msp.m);                   // canonical [0, q_sp)
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.nsel);
     if (wk.pos >= wk.end) return;
+    ReadersGate<G> gate(ldsx);                                    // every transform of the item loop follows an inverse one (ntt_core.hpp)
     // the next item's words are requested into spare registers behind the last per-lane twiddle request of the current
     // transform (WgNttF64::inverse's `before_uniform` hook; see k_ntt_inv_p): the item loop never waits for its input
     auto src_of = [&](u32 item) -> const u64* {
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
         if constexpr (FUSED) {                                    // t_target[d] = a_1[d] . b_1[d]
             const size_t at = ((size_t(ib) * 2 + 1) * a.L + d) * G::N;
             load_product_to_B<G>(v, a.mul_a + at, a.mul_b + at, ldsx, tid, md.m);
-            W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+            W::template inverse<false, typename W::NoHook, false, ReadersGate<G>>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, typename W::NoHook(), 0u, &gate);
         } else if constexpr (G::KL <= 2) {
             // canonical words as they are: the first inverse stage takes X + Y < 2p and |X - Y| < p (f64_arith.hpp)
             const u64 qd = (u64)md.m.p;
@@ -376,10 +379,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_intt
 #pragma unroll
                 for (int r = 0; r < G::E; ++r) raw[r] = (pn + G::idxB(r, 0))[tB];
             };
-            W::template inverse<false, decltype(request_next), (KX_IPRE != 0)>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, request_next);
+            W::template inverse<false, decltype(request_next), (KX_IPRE != 0), ReadersGate<G>>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, request_next, 0u, &gate);
         } else {
             load_natural_to_B<G>(v, a.t_target + size_t(row) * G::N, ldsx, tid, md.m, bad);
-            W::template inverse<false>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc);
+            W::template inverse<false, typename W::NoHook, false, ReadersGate<G>>(v, ldsx, tid, tb + 2 * G::N, tb + 3 * G::N, md.m, md.sc, typename W::NoHook(), 0u, &gate);
         }
         double* cd = a.c + size_t(row) * G::N;
 #pragma unroll
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
     const u32 isp = a.K - 1;
     const KsModF64 msp = a.mods[isp];
     const XcdWalk wk = xcd_walk(a.nb);
+    ReadersGate<G> gate(ldsx);
 #pragma unroll 1
     for (u32 b = wk.pos; b < wk.end; b += wk.step) {
     double acc0[G::E], acc1[G::E];
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
         u32 tsp = KX_ALIASED(16, isp) * 4 * G::N;
         asm volatile("" : "+s"(tsp));
         KX_STAMP(4 * L + 0);
-        ksx_special_down<G, W>(acc0, a.s + (size_t(b) * 2 + 0) * G::N, ldsx, tid, a.tables + tsp, msp);
+        ksx_special_down<G, W>(acc0, a.s + (size_t(b) * 2 + 0) * G::N, ldsx, tid, a.tables + tsp, msp, gate);
     }
     {
         int tid = threadIdx.x;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), KX_WAVES(LOGE)) void k_ksx_spec
         u32 tsp = KX_ALIASED(16, isp) * 4 * G::N;
         asm volatile("" : "+s"(tsp));
         KX_STAMP(4 * L + 4);
-        ksx_special_down<G, W>(acc1, a.s + (size_t(b) * 2 + 1) * G::N, ldsx, tid, a.tables + tsp, msp);
+        ksx_special_down<G, W>(acc1, a.s + (size_t(b) * 2 + 1) * G::N, ldsx, tid, a.tables + tsp, msp, gate);
         KX_STAMP(4 * L + 8);
     }
     }
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_intt(KsArgsX a) {
     extern __shared__ __attribute__((aligned(16))) double ldsx[];
     const XcdWalk wk = xcd_walk(a.nb * a.nsel * 2);
     hxf::RangeMask bad = 0;
+    ReadersGate<G> gate(ldsx);                                    // inverse after inverse in one workgroup (ntt_core.hpp)
 #pragma unroll 1
     for (u32 unit = wk.pos; unit < wk.end; unit += wk.step) {     // unit = (b * nsel + number of d among this launch's limbs) * 2 + h
         int tid = threadIdx.x;
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_intt(KsArgsX a) {
 #pragma unroll
             for (int r = 0; r < G::E; ++r) v[r] = hxf::to_f64_lt52_checked((src + G::idxB(r, 0))[tB], qd, bad);    // canonical words as they are
         }
-        W::template inverse<false>(v, ldsx, tid, tb + 2 * NF, tb + 3 * NF, md.m, md.sc, typename W::NoHook(), h);
+        W::template inverse<false, typename W::NoHook, false, ReadersGate<G>>(v, ldsx, tid, tb + 2 * NF, tb + 3 * NF, md.m, md.sc, typename W::NoHook(), h, &gate);
         double* dst = a.csub + (size_t(row) * 2 + h) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (dst + G::idxA(r, 0))[u32(tid)] = v[r];
@@ -780,6 +785,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
     const u32 L = a.L, isp = a.K - 1;
     const KsModF64 msp = a.mods[isp];
     const XcdWalk wk = xcd_walk(a.nb * 2);
+    ReadersGate<G> gate(ldsx);                                    // the two inverse transforms of a unit follow each other (ntt_core.hpp)
 #pragma unroll 1
     for (u32 unit = wk.pos; unit < wk.end; unit += wk.step) {
         const u32 h = unit & 1, b = unit >> 1;
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(1024, 4) void k_ksh_special(KsArgsX a) {
             asm volatile("" : "+s"(tsp));
             const double* ts = a.tables + tsp;
             double (&acc)[G::E] = k == 0 ? acc0 : acc1;
-            W::template inverse<false>(acc, ldsx, tid, ts + 2 * NF, ts + 3 * NF, msp.m, msp.sc, typename W::NoHook(), h);
+            W::template inverse<false, typename W::NoHook, false, ReadersGate<G>>(acc, ldsx, tid, ts + 2 * NF, ts + 3 * NF, msp.m, msp.sc, typename W::NoHook(), h, &gate);
             double* dst = a.ssub + ((size_t(b) * 2 + k) * 2 + h) * G::N;
 #pragma unroll
             for (int r = 0; r < G::E; ++r) (dst + G::idxA(r, 0))[u32(tid)] = acc[r];

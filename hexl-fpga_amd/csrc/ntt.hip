@@ -409,6 +409,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
+    ReadersGate<G> gate(lds);                                     // inverse after inverse in one workgroup (ntt_core.hpp)
 #pragma unroll 1
     for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
         int tid = threadIdx.x;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 #pragma unroll
             for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
         };
-        WgNttF64<LOGN, LOGE, LAZY, 0, 0, true, HX_FWD_PRIO, 0, false, -1, NTT_ISCHED != 0>::template inverse<false, decltype(request_next), (NTT_IPRE != 0)>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_next);   // no w/p table
+        WgNttF64<LOGN, LOGE, LAZY, 0, 0, true, HX_FWD_PRIO, 0, false, -1, NTT_ISCHED != 0>::template inverse<false, decltype(request_next), (NTT_IPRE != 0), ReadersGate<G>>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_next, 0u, &gate);   // no w/p table
         const bool slow = vote.result(tid);
         if (!slow) {
             fast_path_store<LAZY>(f, px, m, q, [&](int r) { return G::idxA(r, tid); });
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u
         return;
     }
     RangeVote vote(reinterpret_cast<char*>(lds) + G::LDS_USED);
+    ReadersGate<G> gate(lds);                                     // inverse after inverse in one workgroup (ntt_core.hpp)
     // block 1 of a polynomial is requested inside the transform of block 0 (where k_ntt_inv_p requests its next polynomial), block 0 of the
     // NEXT polynomial behind the second transform, pair by pair between the stores; two votes per polynomial, nothing is stored before the
     // second
@@ -559,7 +561,8 @@ __global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u
             u[r] = fast_path_input<LAZY>(raw[r], m);
         }
         vote.cast(out_of_range);
-        W::template inverse<false>(u, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, [&] { request(px + G::N); }, 0u);
+        auto request_other_half = [&] { request(px + G::N); };
+        W::template inverse<false, decltype(request_other_half), false, ReadersGate<G>>(u, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_other_half, 0u, &gate);
         bool slow = vote.result(tid);
         if (!slow) {
             out_of_range = false;
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(1024) void k_ntt_inv_h(u64* __restrict__ x, const u
                 v[r] = fast_path_input<LAZY>(raw[r], m);
             }
             vote.cast(out_of_range);
-            W::template inverse<false>(v, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, typename W::NoHook(), 1u);
+            W::template inverse<false, typename W::NoHook, false, ReadersGate<G>>(v, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, typename W::NoHook(), 1u, &gate);
             slow = vote.result(tid);
         }
         if (slow) {
@@ -753,6 +756,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_ip(u64* __restri
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (p0 + G::idxB(r, 0))[tB];
     }
+    ReadersGate<G> gate(lds);                                     // inverse after inverse in one workgroup (ntt_core.hpp)
 #pragma unroll 1
     for (u32 p = blockIdx.x; p < batch; p += gridDim.x) {
         int tid = threadIdx.x;
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_ip(u64* __restri
 #pragma unroll
         for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
         const u64* tw = iroots + opaque_zero();
-        WgNtt<LOGN, LOGE>::inverse(v, lds, tid, tw, iprecon + (tw - iroots), q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        WgNtt<LOGN, LOGE>::template inverse<false, ReadersGate<G>>(v, lds, tid, tw, iprecon + (tw - iroots), q, inv_n, inv_n_p, inv_n_w, inv_n_w_p, &gate);
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (px + G::idxA(r, 0))[u32(tid)] = v[r];
     }

@@ -305,6 +305,59 @@ __device__ __forceinline__ void redeal_half(V (&v)[G::E], V* lds, int tid, FromI
     swap_halves_if<G>(v, t);
 }
 
+// Readers' gate (round 6). An INVERSE transform ends with its cross-wave exchange: behind the barrier every wave reads words out of every
+// other wave's block. The transform that follows is protected if it is a forward one (its first LDS access is a cross-wave exchange with a
+// LEAD barrier) -- but another INVERSE transform starts with a wave-PRIVATE re-deal, whose writes go to the wave's own block without any
+// barrier: a wave that runs ahead overwrites words a slower wave of the workgroup has not read yet. With one 16-wave workgroup per CU the
+// waves of a SIMD share a phase and a priority and the window (a pass, a store and a partial pass: > 500 instructions) never closed; with
+// several small workgroups per CU it does -- a wave at the low per-pass priority starves behind other workgroups' waves: N = 2048,
+// s'_0 of one instance in a few thousand wrong (tools/soak_ks_random.py found it). A barrier in front of every inverse transform would put
+// the waves of the persistent kernels back in lockstep once per polynomial, so the two halves of one are split instead: a wave ARRIVES
+// (one LDS atomic by lane 0) right behind its cross-wave reads -- a wave's LDS instructions execute in order, so they have been served when
+// the increment is -- and WAITS in front of its next inverse transform's first private write until every wave of the workgroup has arrived
+// as often as it has itself. Arrivals precede the wait by hundreds of instructions: the wait all but never spins, and no wave can wait for
+// an arrival that is behind a barrier it has not passed itself (no deadlock). The counter is the last word of the exchange array, which
+// Geom::pad never reaches (pad(N - 1) = LDS_WORDS - 18).
+struct NoGate {
+    __device__ __forceinline__ void arrive() const {}
+    __device__ __forceinline__ void wait() const {}
+};
+template <class G>
+struct ReadersGate {
+    static_assert(G::pad(G::N - 1) < G::LDS_WORDS - 1, "the counter's word must be outside the exchange slots");
+    static constexpr u32 WAVES = (G::T + 63) / 64;
+    // (half-size exchanges -- N = 32768 in one workgroup -- put barriers around every round: nothing to gate; one-wave workgroups neither)
+    static constexpr bool ON = !G::HALF_ONLY && WAVES > 1;
+    u32* cnt;
+    u32 expect;                                                   // arrivals every wave must have made before this one overwrites its block
+    // (one barrier per kernel; `lds` = the exchange array)
+    __device__ __forceinline__ explicit ReadersGate(void* lds) : cnt(reinterpret_cast<u32*>(static_cast<u64*>(lds) + (G::LDS_WORDS - 1))), expect(0) {
+        if constexpr (ON) {
+            if (threadIdx.x == 0) *cnt = 0;
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ void arrive() {
+        if constexpr (ON) {
+            asm volatile("" ::: "memory");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            expect += WAVES;
+        }
+    }
+    __device__ __forceinline__ void wait() {
+        if constexpr (ON) {
+            asm volatile("" ::: "memory");
+            while (int(u32(__builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) - expect) < 0)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
+    }
+};
+// where a transform arrives / waits: arrive behind a cross-wave exchange of an inverse transform, wait in front of its first re-deal
+template <class Gate> inline constexpr bool gate_on = true;
+template <> inline constexpr bool gate_on<NoGate> = false;
+
 // The re-deal between the full pass on coefficient bits [LO, LO+LOGE) (`idxF<LO>`) and its lower neighbour -- the
 // full pass below it, or the partial pass (B order) when LOWER_IS_B -- in the direction of the transform.
 template <class G, int LO, int LOGE, bool FORWARD, bool LEAD, bool LOWER_IS_B, class V>
@@ -395,28 +448,31 @@ struct WgNtt {
         }
     }
     // PASS counts the full passes after the partial one: active bits [KL + PASS*LOGE, +LOGE)
-    template <int PASS, bool FRESH = false>
+    // `gate` (ReadersGate above): for an inverse transform that may FOLLOW another one in the same workgroup, and for the one it follows
+    template <int PASS, bool FRESH = false, class Gate = NoGate>
     __device__ static __forceinline__ void inv_pass(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
                                                     const u64* iprecon, u64 q, u64 twoq, u64 a, u64 ap,
-                                                    u64 b, u64 bp) {
+                                                    u64 b, u64 bp, Gate* gate = nullptr) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
             constexpr bool LEAD = !(FRESH && PASS == 0);
             prio<HX_IINV_PRIO, PASS + 1>();
+            if constexpr (gate_on<Gate> && PASS == 0 && !G::HALF_ONLY) gate->wait();
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
+            if constexpr (gate_on<Gate> && PASS == G::P - 2 && !G::HALF_ONLY && !G::template wave_private<LO>) gate->arrive();
             const u32 Gp = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             inv_stages<E, 0, LOGE, LO, LOGN, (PASS == G::P - 2)>(v, Gp, iroots, iprecon, q, twoq, a, ap, b, bp);
-            inv_pass<PASS + 1, FRESH>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp);
+            inv_pass<PASS + 1, FRESH, Gate>(v, lds, tid, iroots, iprecon, q, twoq, a, ap, b, bp, gate);
         }
     }
-    template <bool FRESH = false>
+    template <bool FRESH = false, class Gate = NoGate>
     __device__ static __forceinline__ void inverse(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
                                                    const u64* iprecon, u64 q, u64 inv_n, u64 inv_n_p,
-                                                   u64 inv_n_w, u64 inv_n_w_p) {
+                                                   u64 inv_n_w, u64 inv_n_w_p, Gate* gate = nullptr) {
         const u64 twoq = q << 1;
         prio<HX_IINV_PRIO, 0>();
         inv_first<0>(v, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
-        inv_pass<0, FRESH>(v, lds, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+        inv_pass<0, FRESH, Gate>(v, lds, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p, gate);
     }
 };
 

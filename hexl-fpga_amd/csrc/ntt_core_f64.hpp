@@ -422,31 +422,34 @@ struct WgNttF64 {
     // (a persistent kernel's next input) delays nothing -- vector memory returns in order.
     template <int PASS>
     static constexpr bool inv_pass_uniform = (PASS == G::P - 2) || (G::KL + PASS * LOGE >= 6);
-    template <int PASS, bool FRESH = false, class Hook = NoHook, bool IPRE = false>
+    template <int PASS, bool FRESH = false, class Hook = NoHook, bool IPRE = false, class Gate = NoGate>
     __device__ static __forceinline__ void inv_pass(double (&v)[E], double* lds, int tid, const double* iw,
                                                     const double* iwp, const Mod m, const InvScale sc,
-                                                    Hook before_uniform = Hook(), u32 top = 0) {
+                                                    Hook before_uniform = Hook(), u32 top = 0, Gate* gate = nullptr) {
         if constexpr (PASS < G::P - 1) {
             constexpr int LO = G::KL + PASS * LOGE;
             constexpr bool LEAD = !(FRESH && PASS == 0);
             hx_inv_prio<PASS + 1>();
+            // ReadersGate (ntt_core.hpp): wait in front of the first (wave-private) re-deal, arrive behind the cross-wave exchange
+            if constexpr (gate_on<Gate> && PASS == 0 && !G::HALF_ONLY) gate->wait();
             redeal_pass<G, LO, LOGE, false, LEAD, (PASS == 0)>(v, lds, tid);
+            if constexpr (gate_on<Gate> && PASS == G::P - 2 && !G::HALF_ONLY && !G::template wave_private<LO>) gate->arrive();
             if constexpr (inv_pass_uniform<PASS> && (PASS == 0 || !inv_pass_uniform<(PASS > 0 ? PASS - 1 : 0)>)) before_uniform();
             const u32 Gl = (PASS == G::P - 2) ? 0u : (LO >= 6 ? u32(__builtin_amdgcn_readfirstlane(u32(tid) >> LO)) : (u32(tid) >> LO));
             const u32 Gp = ginv<LO, LOGE>(top, Gl);
             // (TOP > 0: the transform's last stage -- the one with n^-1 folded in -- is not among these)
             if constexpr (IPRE && !(PASS == G::P - 2 || LO >= 6)) inv_stages_f64_pre<E, 0, LOGE, LO, FLOGN, false, LAZY, NOWP, IS>(v, Gp, iw, iwp, m, sc);
             else inv_stages_f64<E, 0, LOGE, LO, FLOGN, (PASS == G::P - 2 && TOP == 0), LAZY, (PASS == G::P - 2 || LO >= 6), NOWP, IS>(v, Gp, iw, iwp, m, sc);
-            inv_pass<PASS + 1, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform, top);
+            inv_pass<PASS + 1, FRESH, Hook, IPRE, Gate>(v, lds, tid, iw, iwp, m, sc, before_uniform, top, gate);
         }
     }
-    template <bool FRESH = false, class Hook = NoHook, bool IPRE = false>
+    template <bool FRESH = false, class Hook = NoHook, bool IPRE = false, class Gate = NoGate>
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
                                                    const double* iwp, const Mod m, const InvScale sc,
-                                                   Hook before_uniform = Hook(), u32 top = 0) {
+                                                   Hook before_uniform = Hook(), u32 top = 0, Gate* gate = nullptr) {
         hx_inv_prio<0>();
         inv_first<0, IPRE>(v, tid, iw, iwp, m, sc, top);
-        inv_pass<0, FRESH, Hook, IPRE>(v, lds, tid, iw, iwp, m, sc, before_uniform, top);
+        inv_pass<0, FRESH, Hook, IPRE, Gate>(v, lds, tid, iw, iwp, m, sc, before_uniform, top, gate);
     }
 };
 

@@ -581,6 +581,21 @@ def test_latency_paths_agree_on_one_keyswitch(hx, ctx, dev, orc):
     plan.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"HEXL_KSX_PERSIST": "0"}, {"HEXL_KS_PER_LIMB": "0"}], ids=["default", "one_workgroup_per_item", "plan_wide_tier"])
+def test_inverse_after_inverse_race_many_small_workgroups(env):
+    """Round 6, found by tools/soak_ks_random.py: an inverse transform ends with cross-wave LDS reads, and the wave-private first re-deal
+    of an inverse transform that FOLLOWS it in the same workgroup (k_ksx_special's second one) wrote a fast wave's block while a slow wave
+    was still reading it -- at N = 2048 (eight two-wave workgroups per CU, per-pass wave priorities) 9-27 of 180,000 instances came back
+    with a wrong k = 0 half. ntt_core.hpp ReadersGate closes it; tools/race_probe.py compares every instance of 40 launches of 4,500."""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "race_probe.py"), "2048", "2", "3", "4500", "40"], capture_output=True,
+                         text=True, timeout=600, env=dict(os.environ, **env))
+    print(out.stdout[-600:], out.stderr[-800:])
+    assert out.returncode == 0 and " 0 wrong instances" in out.stdout
+
+
 def _alternative(env, n, L, K, nb, moduli="None", extreme=False):
     """`nb` instances (three distinct ones repeated) through the library in a child process with `env` set, against the oracle
     (`extreme`: keys and inputs from ks_util.extreme_words instead of uniform ones)"""
