@@ -92,6 +92,32 @@ def test_extreme_residues_at_every_tier_top(hx, ctx, dev, orc, limit, n):
         assert (got == want[np.arange(batch) % 9]).all()
 
 
+@pytest.mark.parametrize("n,batch", [(2048, 12000), (2048, 5600), (4096, 6000), (8192, 3000), (16384, 1500)])
+def test_every_polynomial_of_large_persistent_batches(hx, ctx, dev, orc, n, batch):
+    """Round 6 (tools/soak_ntt_random.py): the persistent inverse kernel runs transform after transform in one workgroup, and the first
+    (wave-private) re-deal of a transform overwrote words a slower wave was still reading out of the previous one's cross-wave exchange --
+    at N = 2048, batches of 5,600 / 12,000, one or two polynomials of a launch came back wrong about once a second. Rounds 1-5 compared
+    a sample of each large batch; this compares EVERY polynomial of ten launches (on the device). ntt_core.hpp ReadersGate."""
+    import torch
+    q = orc.primes(2, 51, n)[1]
+    t = orc.HexlTables(n, q)
+    base = np.stack([orc.splitmix(n, 500 + b, q) for b in range(7)])
+    idx = torch.arange(batch, device=dev) % 7
+    x = torch.from_numpy(base.view(np.int64)).to(dev)[idx].contiguous()
+    tabs = [_dev(hx, a, dev) for a in (t.roots, t.precon, t.inv_roots, t.inv_precon)]
+    for fwd in (False, True):
+        want = torch.from_numpy((orc.ntt_fwd if fwd else orc.ntt_inv)(base, t).view(np.int64)).to(dev)[idx]
+        for launch in range(10):
+            d = x.clone()
+            if fwd:
+                ctx.ntt_fwd(d, tabs[0], tabs[1], q, n)
+            else:
+                ctx.ntt_inv(d, tabs[2], tabs[3], q, t.inv_n, t.inv_n_w, n)
+            ctx.sync()
+            wrong = int((d.view(batch, n) != want).any(dim=1).sum())
+            assert wrong == 0, f"{'forward' if fwd else 'inverse'} launch {launch}: {wrong} of {batch} polynomials differ"
+
+
 def test_random_tables_like_benchmark(hx, ctx, dev, orc):
     """benchmark/bench_fwd_ntt.cpp:38-42 feeds RANDOM tables: the kernel must replay the butterflies
     op for op, not rely on the tables being roots of unity"""

@@ -2,8 +2,10 @@
 """Randomised parity soak of the keyswitch against the oracle: random primes = 1 mod 2n of random sizes in [2^27, 2^52) (so every
 FP64 tier and every mix of tiers across the limbs of one plan comes up), random ring dimension, decomposition size and batch --
 batches on both sides of the slot-major threshold, so the slot-major, (b, d)-major and latency kernels all run --, uniform and
-worst-case (ks_util.extreme_words) keys and inputs. Every instance of a batch is one of three distinct ones; all are compared.
-usage: soak_ks_random.py [seconds = 240] [seed]"""
+worst-case (ks_util.extreme_words) keys and inputs; one plan in twelve has 53 ... 59-bit primes (integer kernels); a quarter of the FP64 cases
+go through hexl_multiply_relinearize against the composition of the two oracle calls. Every instance of a batch is one of three distinct
+ones; ALL are compared, on the device, over several launches of the same case (a race shows up in one instance of one launch).
+usage: soak_ks_random.py [seconds = 240] [seed] [launches per case = 3]"""
 import sys
 import time
 from pathlib import Path
@@ -17,6 +19,7 @@ from ks_util import KsCase
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260930
+launches = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda:0")
 ctx = hx.Context(0)
 rng = np.random.default_rng(seed)
@@ -48,8 +51,12 @@ while time.time() - t0 < budget:
     L = int(rng.integers(1, 8))
     K = L + 1 + int(rng.integers(0, 2)) * int(rng.integers(0, 3))
     moduli = []
-    for _ in range(K):
-        moduli.append(random_prime(n, moduli))
+    integer = rng.integers(0, 12) == 0 and n <= 16384             # (the integer kernels stop at N = 16384)
+    if integer:
+        moduli = orc.primes(K, int(rng.integers(53, 60)), n)
+    else:
+        for _ in range(K):
+            moduli.append(random_prime(n, moduli))
     per_cu = max(1, 16384 // n)
     nb = int(rng.choice([1, 2, 3, 5, 17, 40 * per_cu, 70 * per_cu, 300 * per_cu // max(1, L // 2)]))
     extreme = bool(rng.integers(0, 2))
@@ -58,18 +65,44 @@ while time.time() - t0 < budget:
     plan.set_keys(case.keys)
     seen_tiers.update(plan.tiers()[0] if hasattr(plan, "tiers") else [])
     ins = [case.extreme_inputs(orc, b) if extreme else case.inputs(orc, b) for b in range(3)]
-    d_t = hx.as_i64(np.concatenate([ins[b % 3][0] for b in range(nb)])).to(dev)
-    d_r = hx.as_i64(np.concatenate([ins[b % 3][1] for b in range(nb)])).to(dev)
-    plan.keyswitch(d_r, d_t, nb)
-    ctx.sync()
-    out = hx.to_u64(d_r).reshape(nb, -1)
-    want = [case.expected(orc, t, r) for t, r in ins]
-    ok = all(np.array_equal(out[b], want[b % 3]) for b in range(nb))
+    idx = torch.arange(nb, device=dev) % 3
+    fused = (not integer) and rng.integers(0, 4) == 0
+    if fused:                                                      # out = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1): operands = the result-shaped words
+        A = [r for _, r in ins]
+        B = [np.roll(r, 1) for _, r in ins]
+        for i in range(L):                                           # (rolled across a limb boundary: bring the word back below its modulus)
+            for Bv in B:
+                Bv[i * n] %= np.uint64(moduli[i]); Bv[(L + i) * n] %= np.uint64(moduli[i])
+        want = []
+        for a_, b_ in zip(A, B):
+            prod = orc.dyadic(a_, b_, n, case.moduli[:L], exact=True)
+            o = prod[:2 * L * n].copy()
+            orc.keyswitch(o, prod[2 * L * n:].copy(), n, L, K, L + 1, case.moduli, case.keys, case.modswitch)
+            want.append(o)
+        d_a = torch.from_numpy(np.stack(A).view(np.int64)).to(dev)[idx].contiguous()
+        d_b = torch.from_numpy(np.stack(B).view(np.int64)).to(dev)[idx].contiguous()
+    else:
+        want = [case.expected(orc, t, r) for t, r in ins]
+        d_t = torch.from_numpy(np.stack([t for t, _ in ins]).view(np.int64)).to(dev)[idx].contiguous()
+        d_r0 = torch.from_numpy(np.stack([r for _, r in ins]).view(np.int64)).to(dev)[idx].contiguous()
+    d_want = torch.from_numpy(np.stack(want).view(np.int64)).to(dev)[idx]
+    ok = True
+    for _ in range(launches):
+        if fused:
+            d_r = torch.full((nb, 2 * L * n), -1, dtype=torch.int64, device=dev)
+            plan.multiply_relinearize(d_r, d_a, d_b, nb)
+        else:
+            d_r = d_r0.clone()
+            plan.keyswitch(d_r, d_t, nb)
+        ctx.sync()
+        wrong = int((d_r.view(nb, -1) != d_want.view(nb, -1)).any(dim=1).sum())
+        if wrong:
+            ok = False
+            print(f"  {wrong} of {nb} instances wrong in one launch", flush=True)
     cases += 1
     if not ok:
         fails += 1
-        print(f"MISMATCH n={n} L={L} K={K} nb={nb} extreme={extreme} moduli={moduli}", flush=True)
+        print(f"MISMATCH n={n} L={L} K={K} nb={nb} extreme={extreme} fused={fused} moduli={moduli}", flush=True)
     plan.close()
-    del d_t, d_r
 print(f"{cases} random keyswitch cases in {time.time() - t0:.0f} s (seed {seed}), tiers seen {sorted(seen_tiers)}, mismatches: {fails}")
 sys.exit(1 if fails else 0)
