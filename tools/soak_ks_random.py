@@ -66,7 +66,7 @@ while time.time() - t0 < budget:
     seen_tiers.update(plan.tiers()[0] if hasattr(plan, "tiers") else [])
     ins = [case.extreme_inputs(orc, b) if extreme else case.inputs(orc, b) for b in range(3)]
     idx = torch.arange(nb, device=dev) % 3
-    fused = (not integer) and rng.integers(0, 4) == 0
+    fused = (-1 not in plan.tiers()[0]) and rng.integers(0, 4) == 0     # (the integer kernels -- moduli >= 2^52 or HEXL_KS_INT=1 -- have no fused pass)
     if fused:                                                      # out = (a0 b0, a0 b1 + a1 b0) + KeySwitch(a1 b1): operands = the result-shaped words
         A = [r for _, r in ins]
         B = [np.roll(r, 1) for _, r in ins]
