@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -223,8 +225,94 @@ static void test_concurrent_worksize1(int threads, int rounds) {
     for (int id = 0; id < threads; ++id) CHECK(bad[id] == 0, "thread %d saw %d unfinished worksize-1 results", id, bad[id]);
 }
 
+// Randomised windows through the host-pointer API (round 6, after the soaks of tools/ found a one-in-10^4 race in the inverse kernels that
+// the small fixed windows above could not see): random primitive, ring dimension, modulus size and worksize -- up to hundreds of objects,
+// i.e. persistent kernels, several staging sub-batches and many small workgroups per CU --, objects drawn from three distinct inputs,
+// EVERY object of every window compared with the oracle.
+static uint64_t rnd_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() { rnd_state ^= rnd_state << 13; rnd_state ^= rnd_state >> 7; rnd_state ^= rnd_state << 17; return rnd_state; }
+static void stress(double seconds, uint64_t seed) {
+    rnd_state ^= seed * 0x2545F4914F6CDD1Dull;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    size_t windows = 0, objects = 0;
+    const uint64_t sizes[] = {1024, 2048, 2048, 4096, 8192, 16384};
+    const size_t works[] = {1, 2, 3, 7, 16, 33, 64, 130, 257, 600};
+    while (elapsed() < seconds) {
+        const uint64_t n = sizes[rnd() % 6];
+        size_t ws = works[rnd() % 10];
+        const int prim = int(rnd() % 3);                            // 0: keyswitch, 1: _NTT then _INTT, 2: dyadic
+        if (prim == 0) {
+            const uint64_t L = 1 + rnd() % 3, K = L + 1;
+            ws = std::min<size_t>(ws, n >= 16384 ? 130 : 600);
+            KsSetup ks(n, L, K, 11 + rnd() % 1000);
+            vec t[3], r[3], ref[3];
+            for (int v = 0; v < 3; ++v) { ks.make(t[v], r[v], 3 + v + rnd() % 50); ref[v] = r[v]; ks.expect(ref[v], t[v]); }
+            std::vector<vec> rr(ws);
+            for (size_t b = 0; b < ws; ++b) rr[b] = r[b % 3];
+            set_worksize_KeySwitch(ws);
+            for (size_t b = 0; b < ws; ++b)
+                KeySwitch(rr[b].data(), t[b % 3].data(), n, L, K, L + 1, 2, ks.moduli.data(), ks.key_ptrs.data(), ks.msf.data());
+            CHECK(KeySwitchCompleted(), "KeySwitchCompleted");
+            for (size_t b = 0; b < ws; ++b) CHECK(rr[b] == ref[b % 3], "stress keyswitch n=%lu L=%lu worksize %zu obj %zu", n, L, ws, b);
+        } else if (prim == 1) {
+            const unsigned bits = 25 + unsigned(rnd() % 36);
+            uint64_t q;
+            orc_generate_primes(&q, 1, bits, n);
+            Tables tb(n, q);
+            vec x[3], f[3], inv[3];
+            for (int v = 0; v < 3; ++v) {
+                x[v].resize(n); orc_fill_splitmix(x[v].data(), n, 900 + v + rnd() % 100, q);
+                f[v] = x[v]; orc_ntt_fwd(f[v].data(), n, q, tb.roots.data(), tb.precon.data());
+                inv[v] = x[v]; orc_ntt_inv(inv[v].data(), n, q, tb.iroots.data(), tb.iprecon.data(), tb.inv_n, tb.inv_n_w);
+            }
+            ws = std::min<size_t>(ws * 4, 2000);
+            std::vector<vec> a(ws), c(ws);
+            for (size_t b = 0; b < ws; ++b) { a[b] = x[b % 3]; c[b] = x[b % 3]; }
+            _set_worksize_NTT(ws);
+            for (size_t b = 0; b < ws; ++b) _NTT(a[b].data(), tb.roots.data(), tb.precon.data(), q, n);
+            CHECK(_NTTCompleted(), "_NTTCompleted");
+            _set_worksize_INTT(ws);
+            for (size_t b = 0; b < ws; ++b) _INTT(c[b].data(), tb.iroots.data(), tb.iprecon.data(), q, tb.inv_n, tb.inv_n_w, n);
+            CHECK(_INTTCompleted(), "_INTTCompleted");
+            for (size_t b = 0; b < ws; ++b) {
+                CHECK(a[b] == f[b % 3], "stress _NTT n=%lu bits=%u worksize %zu obj %zu", n, bits, ws, b);
+                CHECK(c[b] == inv[b % 3], "stress _INTT n=%lu bits=%u worksize %zu obj %zu", n, bits, ws, b);
+            }
+        } else {
+            const uint64_t nm = 1 + rnd() % 4;
+            ws = std::min<size_t>(ws, 130);
+            vec mod(nm);
+            orc_generate_primes(mod.data(), nm, 30 + unsigned(rnd() % 30), n);
+            vec a[3], b[3], ref[3];
+            for (int v = 0; v < 3; ++v) {
+                a[v].resize(2 * nm * n); b[v].resize(2 * nm * n); ref[v].resize(3 * nm * n);
+                for (uint64_t m = 0; m < 2 * nm; ++m) {
+                    orc_fill_splitmix(&a[v][m * n], n, 40 + v * 16 + m, mod[m % nm]);
+                    orc_fill_splitmix(&b[v][m * n], n, 140 + v * 16 + m, mod[m % nm]);
+                }
+                orc_dyadic_multiply(ref[v].data(), a[v].data(), b[v].data(), n, mod.data(), nm, 1);
+            }
+            std::vector<vec> out(ws, vec(3 * nm * n));
+            set_worksize_DyadicMultiply(ws);
+            for (size_t k = 0; k < ws; ++k) DyadicMultiply(out[k].data(), a[k % 3].data(), b[k % 3].data(), n, mod.data(), nm);
+            CHECK(DyadicMultiplyCompleted(), "DyadicMultiplyCompleted");
+            for (size_t k = 0; k < ws; ++k) CHECK(out[k] == ref[k % 3], "stress dyadic n=%lu nm=%lu worksize %zu obj %zu", n, nm, ws, k);
+        }
+        ++windows; objects += ws;
+        if (failures > 20) break;
+    }
+    std::printf("stress: %zu windows, %zu objects in %.0f s (seed %lu)\n", windows, objects, elapsed(), (unsigned long)seed);
+}
+
 int main(int argc, char** argv) {
     acquire_FPGA_resources();
+    if (argc > 1 && !std::strcmp(argv[1], "stress")) {            // stress [seconds] [seed]
+        stress(argc > 2 ? atof(argv[2]) : 30.0, argc > 3 ? strtoull(argv[3], nullptr, 10) : 1);
+        release_FPGA_resources();
+        std::printf(failures ? "CXX API: %d FAILURE(S)\n" : "CXX API: ALL PASSED\n", failures);
+        return failures ? 1 : 0;
+    }
     if (argc > 1 && !std::strcmp(argv[1], "threads")) {           // concurrent worksize-1 callers: threads [count] [rounds]
         test_concurrent_worksize1(argc > 2 ? atoi(argv[2]) : 4, argc > 3 ? atoi(argv[3]) : 20);
         release_FPGA_resources();

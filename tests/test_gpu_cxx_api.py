@@ -41,6 +41,17 @@ def test_aliased_results_across_staging_sub_batches():
     assert out.returncode == 0 and "ALL PASSED" in out.stdout
 
 
+@pytest.mark.parametrize("env", [{}, {"NUM_DEV": "2", "HEXL_DEV_ALIAS": "1", "HEXL_HOST_SUB_MB": "8"}], ids=["one_device", "two_runners_small_slabs"])
+def test_randomised_windows_every_object_checked(env):
+    """round 6: random primitive / ring dimension / modulus size / worksize (up to hundreds of objects: persistent kernels, several staging
+    sub-batches, many small workgroups per CU) through the host-pointer API, EVERY object of every window against the oracle"""
+    import os
+    exe = ROOT / "tests" / "cpp" / "test_cxx_api"
+    out = subprocess.run([str(exe), "stress", "20", "7"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "ALL PASSED" in out.stdout
+
+
 def test_two_device_contexts_on_one_gpu():
     """NUM_DEV=2 with HEXL_DEV_ALIAS=1: two runner threads, two contexts and two plan caches on the one visible GPU --
     the in-process multi-device path (DevicePool, host/src/fpga.cpp:1646-1673) executes for real, including the
