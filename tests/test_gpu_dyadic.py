@@ -52,6 +52,30 @@ def test_prime_moduli_vs_oracle(hx, ctx, dev, orc, bits):
         assert np.array_equal(exact, orc.dyadic(a[sl], b[sl], n, mod1, exact=False))   # reference MultMod, in domain
 
 
+def test_moduli_between_2p61_and_2p62(hx, ctx, dev, orc):
+    """Round 6 (tools/soak_dyadic_random.py): the Barrett quotient estimate of mod_ops.hpp:49-83 can fall short by TWO for a modulus of 62
+    bits -- one operand pair in ~10^3 came back in [q, 2q) with the reference's single conditional subtraction. Moduli all over
+    [2^61, 2^62) (primes, even values, 2^62 - 1), operands uniform below q, at q - 1 and anywhere in 64 bits: the mathematical result."""
+    n, nm = 4096, 6
+    rng = np.random.default_rng(62)
+    mod = np.array([(1 << 62) - 1, (1 << 61), (1 << 61) + 1, 4475467519117804091, 3503029193451124011, orc.primes(1, 62, n)[0]], dtype=np.uint64)
+    for kind in range(3):
+        if kind == 0:
+            a = np.concatenate([rng.integers(0, int(m), size=n, dtype=np.uint64) for _p in range(2) for m in mod])
+            b = np.concatenate([rng.integers(0, int(m), size=n, dtype=np.uint64) for _p in range(2) for m in mod])
+        elif kind == 1:
+            a = np.concatenate([np.full(n, int(m) - 1, dtype=np.uint64) - rng.integers(0, 3, size=n, dtype=np.uint64) for _p in range(2) for m in mod])
+            b = np.concatenate([np.full(n, int(m) - 1, dtype=np.uint64) - rng.integers(0, 3, size=n, dtype=np.uint64) for _p in range(2) for m in mod])
+        else:
+            a = rng.integers(0, 2**64 - 1, size=2 * nm * n, dtype=np.uint64)
+            b = rng.integers(0, 2**64 - 1, size=2 * nm * n, dtype=np.uint64)
+        got = gpu_dyadic(hx, ctx, dev, a, b, mod, n, nm).reshape(3, nm, n).astype(object)
+        A, B, M = a.reshape(2, nm, n).astype(object), b.reshape(2, nm, n).astype(object), mod.astype(object)[:, None]
+        assert np.array_equal(got[0], (A[0] * B[0]) % M) and np.array_equal(got[2], (A[1] * B[1]) % M), f"operand kind {kind}"
+        assert np.array_equal(got[1], (A[0] * B[1] + A[1] * B[0]) % M), f"operand kind {kind}"
+        assert np.array_equal(got.astype(np.uint64).reshape(-1), orc.dyadic(a, b, n, mod, exact=True))
+
+
 def test_arbitrary_64bit_operands(hx, ctx, dev, orc):
     n, nm = 2048, 3
     mod = np.array([3, 2**61 - 1, 1000003], dtype=np.uint64)

@@ -46,6 +46,7 @@ def random_prime(n, used):
 t0 = time.time()
 cases = fails = 0
 seen_tiers = set()
+prev = None                                                       # the previous case, kept alive: its plan is launched again between this case's launches
 while time.time() - t0 < budget:
     n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 16384, 16384, 32768]))
     L = int(rng.integers(1, 8))
@@ -97,8 +98,16 @@ while time.time() - t0 < budget:
         else:
             d_r = d_r0.clone()
             plan.keyswitch(d_r, d_t, nb)
+        if prev is not None:                                       # two plans on one context, launched back to back (scratch growth, plan switches)
+            p_r = prev["r0"].clone()
+            prev["plan"].keyswitch(p_r, prev["t"], prev["nb"])
         ctx.sync()
         wrong = int((d_r.view(nb, -1) != d_want.view(nb, -1)).any(dim=1).sum())
+        if prev is not None:
+            pw = int((p_r.view(prev["nb"], -1) != prev["want"].view(prev["nb"], -1)).any(dim=1).sum())
+            if pw:
+                ok = False
+                print(f"  {pw} of {prev['nb']} instances of the PREVIOUS case's plan wrong when interleaved ({prev['desc']})", flush=True)
         if wrong:
             ok = False
             print(f"  {wrong} of {nb} instances wrong in one launch", flush=True)
@@ -106,6 +115,12 @@ while time.time() - t0 < budget:
     if not ok:
         fails += 1
         print(f"MISMATCH n={n} L={L} K={K} nb={nb} extreme={extreme} fused={fused} moduli={moduli}", flush=True)
-    plan.close()
+    if prev is not None:
+        prev["plan"].close()
+        prev = None
+    if not fused and rng.integers(0, 2):
+        prev = {"plan": plan, "r0": d_r0, "t": d_t, "nb": nb, "want": d_want, "desc": f"n={n} L={L} K={K} nb={nb} moduli={moduli}"}
+    else:
+        plan.close()
 print(f"{cases} random keyswitch cases in {time.time() - t0:.0f} s (seed {seed}), tiers seen {sorted(seen_tiers)}, mismatches: {fails}")
 sys.exit(1 if fails else 0)

@@ -38,6 +38,9 @@ while time.time() - t0 < budget:
     if q >= (1 << 62):
         continue
     t = orc.HexlTables(n, q)
+    if rng.integers(0, 6) == 0:                                    # tables that are NOT Shoup tables (benchmark/bench_fwd_ntt.cpp:36-42): the integer
+        for a in (t.roots, t.precon, t.inv_roots, t.inv_precon):   # butterflies replay them op for op; also exercises the hint / violation-counter logic,
+            a[:] = orc.splitmix(n, int(rng.integers(1, 1 << 30)), q)   # the allocator hands the next case the same device addresses with other contents
     nuniq = 7
     base = np.stack([orc.splitmix(n, int(rng.integers(1, 1 << 30)), q) for _ in range(nuniq)])
     base[0, :4] = np.array([q - 1, 0, q // 2, q // 2 + 1], dtype=np.uint64)
