@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity soak of the keyswitch against the oracle: random primes = 1 mod 2n of random sizes in [2^27, 2^52) (so every
+"""Randomised parity soak of the keyswitch against the oracle: random primes = 1 mod 2n of random sizes in [2^17, 2^52) (so every
 FP64 tier and every mix of tiers across the limbs of one plan comes up), random ring dimension, decomposition size and batch --
 batches on both sides of the slot-major threshold, so the slot-major, (b, d)-major and latency kernels all run --, uniform and
 worst-case (ks_util.extreme_words) keys and inputs; one plan in twelve has 53 ... 59-bit primes (integer kernels); a quarter of the FP64 cases
@@ -34,12 +34,12 @@ def random_prime(n, used):
         elif kind == 1:                                             # just above a tier top (not above 2^52)
             v = int(EDGES[rng.integers(0, 3)]) + int(rng.integers(1, 1 << 30))
         else:                                                       # any size from 27 bits up
-            b = int(rng.integers(27, 53))
+            b = int(rng.integers(18, 53))                           # (hexl_ks_plan_create takes moduli from 2^16 up)
             v = int(rng.integers(1 << (b - 1), 1 << b))
         v = v // (2 * n) * (2 * n) + 1
-        while v > (1 << 26) and (v in used or not orc.orc().orc_is_prime(v)):
+        while v > (1 << 17) and (v in used or not orc.orc().orc_is_prime(v)):
             v -= 2 * n
-        if v > (1 << 26) and v < (1 << 52):
+        if v > (1 << 17) and v < (1 << 52):
             return v
 
 
