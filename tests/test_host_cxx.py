@@ -50,3 +50,10 @@ def test_concurrent_worksize1_callers_wait_for_their_own_object(exe):
     done. Device 0 is 8x slower here, so later objects on the other devices finish first -- a completion counter would
     release the caller early; tickets retire in order."""
     run(exe, ["threads", "4", "15"], NUM_DEV=3, FAKE_DELAY_US=300, FAKE_DELAY_DEV0_X=8)
+
+
+@pytest.mark.parametrize("num_dev", [1, 3])
+def test_randomised_windows_under_tsan(exe, num_dev):
+    """round 6: the driver's stress mode (random primitive / ring dimension / worksize up to hundreds of objects, every object against
+    the oracle) on the real host layer: FIFO, runs of compatible objects, sharding over the runners, completion -- under ThreadSanitizer"""
+    run(exe, ["stress", "8", str(num_dev)], NUM_DEV=num_dev)
