@@ -54,7 +54,7 @@ __device__ __forceinline__ u64 reduce_operand(u64 x, u64 q, u64 mu) {
 // mod_ops.hpp:49-83 with both operands already < q. The quotient estimate c3 falls short of floor(x y / q) by less than
 // 1/2 + x y / 2^(k + 62) + 1 (k = bit length of q: the truncation of c1, of barr_lo, the final floor) -- at most ONE for q < 2^61, the
 // range HEXL's EltwiseMultMod documents and the reference's single conditional subtraction (:82) covers, but up to TWO for q in
-// [2^61, 2^62): there x y mod q came back as a value in [q, 2q) for about one operand pair in 10^3 (tools/soak_dyadic_random.py,
+// [2^61, 2^62): there x y mod q came back as a value in [q, 2q) for about one operand pair in 10^4 (tools/soak_dyadic_random.py,
 // round 6; the reference's own kernel does the same). The second subtraction makes the result the mathematical one -- what the
 // reference's test model computes (tests/test_dyadic_multiply.cpp:59-82) -- for every modulus in [2, 2^62). (lo - c3 q < 3 q < 2^64.)
 __device__ __forceinline__ u64 mulmod_barrett(u64 x, u64 y, u64 q, u32 len, u64 barr_lo) {

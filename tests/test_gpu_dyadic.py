@@ -54,9 +54,9 @@ def test_prime_moduli_vs_oracle(hx, ctx, dev, orc, bits):
 
 def test_moduli_between_2p61_and_2p62(hx, ctx, dev, orc):
     """Round 6 (tools/soak_dyadic_random.py): the Barrett quotient estimate of mod_ops.hpp:49-83 can fall short by TWO for a modulus of 62
-    bits -- one operand pair in ~10^3 came back in [q, 2q) with the reference's single conditional subtraction. Moduli all over
+    bits -- one operand pair in ~10^4 came back in [q, 2q) with the reference's single conditional subtraction. Moduli all over
     [2^61, 2^62) (primes, even values, 2^62 - 1), operands uniform below q, at q - 1 and anywhere in 64 bits: the mathematical result."""
-    n, nm = 4096, 6
+    n, nm = 16384, 6                                              # (~10 words of these 300 k differed before the fix)
     rng = np.random.default_rng(62)
     mod = np.array([(1 << 62) - 1, (1 << 61), (1 << 61) + 1, 4475467519117804091, 3503029193451124011, orc.primes(1, 62, n)[0]], dtype=np.uint64)
     for kind in range(3):
