@@ -67,6 +67,17 @@ def inverse_events(g, wave, gate, fresh=False):
     return ev
 
 
+def staging_events(g, wave, kind):
+    """the other LDS users of the keyswitch kernels at rings whose partial pass leaves a lane more than four words (KL > 2):
+    `load` = load_natural_to_B / load_product_to_B (redeal_x<false, LEAD>: A positions in, B positions out) in front of an inverse transform;
+    `down` = ksx_down_round's read-modify-write of `result` through LDS behind a forward transform"""
+    A = g.words(lambda r, t: r * g.T + t, wave)
+    B = g.words(lambda r, t: g.idxB(r, t), wave)
+    if kind == "load":
+        return [("BAR", None), ("W", A), ("BAR", None), ("R", B)]
+    return [("BAR", None), ("W", A), ("BAR", None), ("R", B), ("W", B), ("BAR", None), ("R", A)]
+
+
 def races(g, kinds, gate):
     """unordered conflicting pairs over the transforms `kinds` run back to back by one workgroup"""
     waves = (g.T + 63) // 64
@@ -74,7 +85,7 @@ def races(g, kinds, gate):
     for w in range(waves):
         ev = []
         for k in kinds:
-            ev += forward_events(g, w) if k == "fwd" else inverse_events(g, w, gate)
+            ev += forward_events(g, w) if k == "fwd" else inverse_events(g, w, gate) if k == "inv" else staging_events(g, w, k)
         # annotate: barriers passed, own arrivals made, arrivals of everybody this wave has waited for
         out, bars, arrived, waited = [], 0, 0, 0
         for kind, words in ev:
@@ -119,6 +130,19 @@ def test_ownership_maps_are_bijections(logn, loge):
                                    ("fwd", "inv", "inv", "fwd", "inv")])
 def test_consecutive_transforms_are_ordered_with_the_gate(logn, loge, kinds):
     assert races(Geom(logn, loge), kinds, gate=True) == []
+
+
+@pytest.mark.parametrize("logn,loge", [(11, 4), (12, 4)])
+@pytest.mark.parametrize("kinds", [("fwd", "down", "fwd", "down", "fwd"),             # k_ksx_main at N = 2048 / 4096: rounds, then the two mod-down rounds
+                                   ("load", "inv", "load", "inv"),                    # k_ksx_intt's item loop there
+                                   ("fwd", "fwd", "inv", "inv", "fwd")])              # k_ksx_special: rounds, the two inverse transforms, the next instance
+@pytest.mark.parametrize("gate", [True, False])
+def test_kernel_sequences_with_the_staging_phases(logn, loge, kinds, gate):
+    found = races(Geom(logn, loge), kinds, gate)
+    if gate or kinds[0] == "load" or "down" in kinds:
+        assert found == []                                            # (the staging phases bring their own barriers)
+    else:
+        assert found                                                  # k_ksx_special without the gate: the round-6 race
 
 
 @pytest.mark.parametrize("logn,loge", GEOMS)
