@@ -123,13 +123,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ks_modup(KsArgs a) {
     } else {
         // special-prime limb: INTT, then + floor(q_sp/2) mod q_sp (intt2_redu.hpp:25,43)
         const u64* it = tb + opaque_zero() + 2 * G::N;
-        W::inverse(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        W::template inverse<false, OrderedByCaller>(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);   // (behind forward transforms)
         u64* s0 = a.s + (size_t(b) * 2 + 0) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) s0[G::idxA(r, tid)] = csub(acc0[r] + md.half, q);
         it = tb + opaque_zero() + 2 * G::N;
         __syncthreads();                                // inverse after inverse: the first one's cross-wave readers (ntt_core.hpp ReadersGate; once per instance here)
-        W::inverse(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        W::template inverse<false, OrderedByCaller>(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);   // (behind the barrier above)
         u64* s1 = a.s + (size_t(b) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) s1[G::idxA(r, tid)] = csub(acc1[r] + md.half, q);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_special(KsArgs a) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const u64* it = a.tables + size_t(isp) * 4 * G::N + opaque_zero() + 2 * G::N;
-        W::inverse(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        W::template inverse<false, OrderedByCaller>(acc0, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);   // (behind forward transforms)
         u64* s0 = a.s + (size_t(b) * 2 + 0) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (s0 + G::idxA(r, 0))[u32(tid)] = csub(acc0[r] + md.half, q);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ksi_special(KsArgs a) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const u64* it = a.tables + size_t(isp) * 4 * G::N + opaque_zero() + 2 * G::N;
-        W::inverse(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);
+        W::template inverse<false, OrderedByCaller>(acc1, lds, tid, it, it + G::N, q, md.inv_n, md.inv_n_p, md.inv_n_w, md.inv_n_w_p);   // (behind the barrier above)
         u64* s1 = a.s + (size_t(b) * 2 + 1) * G::N;
 #pragma unroll
         for (int r = 0; r < G::E; ++r) (s1 + G::idxA(r, 0))[u32(tid)] = csub(acc1[r] + md.half, q);

@@ -140,7 +140,7 @@ __device__ __attribute__((noinline)) void slow_inv(u64* px, u64* lds, const u64*
 #pragma unroll
     for (int r = 0; r < G::E; ++r) v[r] = px[G::idxB(r, tid)];
     __syncthreads();
-    WgNtt<LOGN, LOGE>::inverse(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);
+    WgNtt<LOGN, LOGE>::template inverse<false, OrderedByCaller>(v, lds, tid, iroots, iprecon, q, inv_n, inv_n_p, inv_n_w, inv_n_w_p);   // (the barrier above)
 #pragma unroll
     for (int r = 0; r < G::E; ++r) px[G::idxA(r, tid)] = v[r];
 }

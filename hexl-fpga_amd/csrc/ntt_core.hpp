@@ -357,6 +357,12 @@ struct ReadersGate {
 // where a transform arrives / waits: arrive behind a cross-wave exchange of an inverse transform, wait in front of its first re-deal
 template <class Gate> inline constexpr bool gate_on = true;
 template <> inline constexpr bool gate_on<NoGate> = false;
+// An inverse transform that is not the only LDS user of its kernel (FRESH = false) has to NAME what orders it behind an earlier inverse
+// transform's cross-wave reads -- a ReadersGate, or this tag: "a forward transform or a barrier of the caller lies in between".
+// (inverse<false> with neither does not compile: the hole of round 6 was a default.)
+struct OrderedByCaller : NoGate {};
+template <> inline constexpr bool gate_on<OrderedByCaller> = false;
+template <bool FRESH, class Gate> inline constexpr bool inverse_is_ordered = FRESH || gate_on<Gate> || __is_same(Gate, OrderedByCaller);
 
 // The re-deal between the full pass on coefficient bits [LO, LO+LOGE) (`idxF<LO>`) and its lower neighbour -- the
 // full pass below it, or the partial pass (B order) when LOWER_IS_B -- in the direction of the transform.
@@ -469,6 +475,7 @@ struct WgNtt {
     __device__ static __forceinline__ void inverse(u64 (&v)[E], u64* lds, int tid, const u64* iroots,
                                                    const u64* iprecon, u64 q, u64 inv_n, u64 inv_n_p,
                                                    u64 inv_n_w, u64 inv_n_w_p, Gate* gate = nullptr) {
+        static_assert(inverse_is_ordered<FRESH, Gate>, "inverse<false>: pass a ReadersGate, or OrderedByCaller if a forward transform or a barrier precedes");
         const u64 twoq = q << 1;
         prio<HX_IINV_PRIO, 0>();
         inv_first<0>(v, tid, iroots, iprecon, q, twoq, inv_n, inv_n_p, inv_n_w, inv_n_w_p);

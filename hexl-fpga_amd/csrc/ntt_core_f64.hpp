@@ -447,6 +447,7 @@ struct WgNttF64 {
     __device__ static __forceinline__ void inverse(double (&v)[E], double* lds, int tid, const double* iw,
                                                    const double* iwp, const Mod m, const InvScale sc,
                                                    Hook before_uniform = Hook(), u32 top = 0, Gate* gate = nullptr) {
+        static_assert(inverse_is_ordered<FRESH, Gate>, "inverse<false>: pass a ReadersGate, or OrderedByCaller if a forward transform or a barrier precedes");
         hx_inv_prio<0>();
         inv_first<0, IPRE>(v, tid, iw, iwp, m, sc, top);
         inv_pass<0, FRESH, Hook, IPRE, Gate>(v, lds, tid, iw, iwp, m, sc, before_uniform, top, gate);
