@@ -240,3 +240,32 @@ def test_baseline_shape_against_a_coefficient_domain_model(orc, L, K):
             got = intt(np.array(delta, dtype=np.uint64), i)
             for j in sample:
                 assert int(got[j]) == (P[j] - tc[j]) * inv % qs[i], (k, i, j)                # ms.hpp:70-82
+
+
+def test_oracle_vs_independent_model_on_random_mixed_moduli(orc):
+    """Round 6: the GPU soaks (tools/soak_ks_random.py) compare the kernels with the oracle on random moduli of 18 ... 52 bits in any mix and
+    with key_modulus_size up to decomp + 3; here the ORACLE is compared with the pure-Python big-integer model on the same distribution
+    (small rings, uniform and worst-case data) -- 1,695 cases of it ran clean in 120 s when this was written, 80 are repeated here"""
+    rng = np.random.default_rng(123)
+
+    def random_prime(n, used):
+        while True:
+            b = int(rng.integers(18, 53))
+            v = int(rng.integers(1 << (b - 1), 1 << b)) // (2 * n) * (2 * n) + 1
+            while v > (1 << 17) and (v in used or not orc.orc().orc_is_prime(v)):
+                v -= 2 * n
+            if v > (1 << 17):
+                return v
+
+    for _ in range(80):
+        n = int(rng.choice([16, 32, 64]))
+        L = int(rng.integers(1, 5))
+        K = L + 1 + int(rng.integers(0, 3))
+        moduli = []
+        for _k in range(K):
+            moduli.append(random_prime(n, moduli))
+        extreme = bool(rng.integers(0, 2))
+        case = KsCase(orc, n, L, K, seed=int(rng.integers(1, 1000)), moduli=moduli, extreme_keys=extreme)
+        b = int(rng.integers(0, 9))
+        t, r = case.extreme_inputs(orc, b) if extreme else case.inputs(orc, b)
+        assert np.array_equal(case.expected(orc, t, r), model_keyswitch(case, t, r, orc)), (n, L, K, moduli, extreme)
