@@ -432,6 +432,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void k_ntt_inv_p(u64* __restric
 #pragma unroll
             for (int r = 0; r < G::E; ++r) raw[r] = (pnx + G::idxB(r, 0))[tB];
         };
+        // (N = 32768 in one workgroup, HEXL_NTT_HALVES=0 only: the half-size exchanges bring barriers of their own except behind an inverse
+        // transform's last round and in front of its first, wave-private, one -- the same inverse-after-inverse hole, closed with a barrier here)
+        if constexpr (G::HALF_ONLY) __syncthreads();
         WgNttF64<LOGN, LOGE, LAZY, 0, 0, true, HX_FWD_PRIO, 0, false, -1, NTT_ISCHED != 0>::template inverse<false, decltype(request_next), (NTT_IPRE != 0), ReadersGate<G>>(f, reinterpret_cast<double*>(lds), tid, w, wp, m, sc, request_next, 0u, &gate);   // no w/p table
         const bool slow = vote.result(tid);
         if (!slow) {

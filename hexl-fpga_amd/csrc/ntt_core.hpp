@@ -326,7 +326,8 @@ template <class G>
 struct ReadersGate {
     static_assert(G::pad(G::N - 1) < G::LDS_WORDS - 1, "the counter's word must be outside the exchange slots");
     static constexpr u32 WAVES = (G::T + 63) / 64;
-    // (half-size exchanges -- N = 32768 in one workgroup -- put barriers around every round: nothing to gate; one-wave workgroups neither)
+    // (half-size exchanges -- N = 32768 in one workgroup -- are not gated: their slots change from re-deal to re-deal; the one kernel that runs
+    // inverse after inverse on them, k_ntt_inv_p<15, 5> under HEXL_NTT_HALVES=0, has a barrier per polynomial. One-wave workgroups need nothing.)
     static constexpr bool ON = !G::HALF_ONLY && WAVES > 1;
     u32* cnt;
     u32 expect;                                                   // arrivals every wave must have made before this one overwrites its block
